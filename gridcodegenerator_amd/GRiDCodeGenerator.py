@@ -1,0 +1,258 @@
+"""GRiDCodeGenerator for AMD MI355X (gfx950 / CDNA4).
+
+Keeps the reference's Python entry point (reference GRiDCodeGenerator.py:54 ctor, :309 gen_all_code) and the
+emitted ``ALGORITHM_inner / _device / _kernel / host`` surface (reference :312-380), but emits HIP designed for
+wave64 hardware instead of CUDA:
+
+    from gridcodegenerator_amd import GRiDCodeGenerator
+    GRiDCodeGenerator(robot).gen_all_code()      # writes <FILE_NAMESPACE>.cuh in the cwd (HIP source)
+
+``robot`` is any object offering the URDFParser-style getters; gridcodegenerator_amd.robot
+provides one (RobotModel) for JSON/URDF descriptions.
+"""
+import numpy as np
+
+from .robot import DuckRobot
+
+
+class GRiDCodeGenerator:
+    # emission primitives, device math, model constants (free functions taking self, like the reference's layout)
+    from .helpers import gen_add_code_line, gen_add_code_lines, gen_add_end_control_flow, gen_add_end_function, \
+        gen_add_func_doc, gen_add_serial_ops, gen_add_parallel_loop, gen_add_sync, gen_var_in_list, gen_var_not_in_list, \
+        gen_lane_mask_test, gen_kernel_prologue, gen_kernel_load_inputs, gen_kernel_save_result, \
+        gen_spatial_algebra_helpers, gen_mx_func_call_for_cpp, \
+        gen_lds_layout, gen_get_XI_size, gen_topology_helpers_size, gen_init_XImats, gen_init_topology_helpers, gen_init_robotModel, \
+        gen_load_update_XImats_helpers_function_call, gen_load_update_XImats_helpers, gen_topology_sparsity_helpers_python
+
+    # algorithms on the forward-dynamics-gradient path
+    from .algorithms import gen_tree_traversal, \
+        gen_inverse_dynamics_inner_temp_mem_size, gen_inverse_dynamics_inner_function_call, gen_inverse_dynamics_inner, \
+        gen_inverse_dynamics_kernel, gen_inverse_dynamics_host, gen_inverse_dynamics, \
+        gen_direct_minv_inner_temp_mem_size, gen_direct_minv_inner_function_call, gen_direct_minv_inner, \
+        gen_direct_minv_kernel, gen_direct_minv_host, gen_direct_minv, \
+        gen_forward_dynamics_inner_temp_mem_size, gen_forward_dynamics_finish_function_call, gen_forward_dynamics_finish, \
+        gen_forward_dynamics_inner_function_call, gen_forward_dynamics_inner, gen_forward_dynamics_kernel, \
+        gen_forward_dynamics_host, gen_forward_dynamics, \
+        gen_inverse_dynamics_gradient_inner_temp_mem_size, gen_inverse_dynamics_gradient_kernel_max_temp_mem_size, \
+        gen_inverse_dynamics_gradient_inner_function_call, gen_inverse_dynamics_gradient_inner, \
+        gen_inverse_dynamics_gradient_kernel, gen_inverse_dynamics_gradient_host, gen_inverse_dynamics_gradient, \
+        gen_forward_dynamics_gradient_inner_temp_mem_size, gen_forward_dynamics_gradient_kernel_max_temp_mem_size, \
+        gen_forward_dynamics_gradient_inner_python, gen_forward_dynamics_gradient_device, gen_forward_dynamics_gradient_kernel, \
+        gen_forward_dynamics_gradient_host, gen_forward_dynamics_gradient, gen_forward_dynamics_gradient_device_function_call
+
+    def __init__(self, robotObj, DEBUG_MODE=False, NEED_PRINT_MAT=False, USE_DYNAMIC_SHARED_MEM=True, FILE_NAMESPACE="grid"):
+        self.robot = robotObj
+        self.model = DuckRobot(robotObj)  # numeric tables; raises for robots outside the supported joint models
+        self.code_str = ""
+        self.indent_level = 0
+        self.DEBUG_MODE = DEBUG_MODE
+        self.gen_print_mat = DEBUG_MODE or NEED_PRINT_MAT
+        self.use_dynamic_shared_mem_flag = True  # the lane-group kernels always carve their LDS slice from dynamic LDS
+        self.file_namespace = FILE_NAMESPACE
+        n = self.model.n
+        if n > 64:
+            raise NotImplementedError("robots with more than 64 joints need more than one wavefront per solve")
+        lanes = 8
+        while lanes < n:
+            lanes *= 2
+        self.lanes_per_solve = lanes          # lane j of a group <-> joint j; 6 lanes also carry the articulated inertia columns
+        self.suggested_threads = 256
+        self.max_threads = 512                # __launch_bounds__: keeps 256 VGPRs available per lane
+
+    # ------------------------------------------------------------------ file prologue
+    def gen_add_includes(self, use_thread_group=False):
+        self.gen_add_code_line("")
+        self.gen_add_code_lines(["#include <assert.h>", "#include <stdio.h>", "#include <stdlib.h>", "#include <math.h>", "#include <time.h>",
+                                 "#include <hip/hip_runtime.h>"])
+        self.gen_add_code_lines(["// single kernel timing helper code",
+                                 "#define time_delta_us_timespec(start,end) (1e6*static_cast<double>(end.tv_sec - start.tv_sec)+1e-3*static_cast<double>(end.tv_nsec - start.tv_nsec))"])
+        self.gen_add_code_line("")
+        self.gen_add_code_line("#define XIMAT_SIZE 36")
+
+    def gen_add_gpu_err(self):
+        self.gen_add_func_doc("Check for runtime errors using the HIP API", [], [], None)
+        self.gen_add_code_line("__host__")
+        self.gen_add_code_line("inline void gpuAssert(hipError_t code, const char *file, const int line, bool abort=true){", True)
+        self.gen_add_code_line("if (code != hipSuccess){", True)
+        self.gen_add_code_line("fprintf(stderr,\"GPUassert: %s %s %d\\n\", hipGetErrorString(code), file, line);")
+        self.gen_add_code_line("if (abort){hipDeviceReset(); exit(code);}")
+        self.gen_add_end_control_flow()
+        self.gen_add_end_control_flow()
+        self.gen_add_code_line("#define gpuErrchk(err) {gpuAssert(err, __FILE__, __LINE__);}")
+        self.gen_add_code_line("")
+        if self.gen_print_mat:
+            for const in ("", "const "):
+                self.gen_add_code_line("template <typename T, int M, int N>")
+                self.gen_add_code_line("__host__ __device__")
+                self.gen_add_code_line("void printMat(" + const + "T *A, int lda){", True)
+                self.gen_add_code_line("for(int i=0; i<M; i++){", True)
+                self.gen_add_code_line("for(int j=0; j<N; j++){printf(\"%.4f \",A[i + lda*j]);}")
+                self.gen_add_code_line("printf(\"\\n\");")
+                self.gen_add_end_control_flow()
+                self.gen_add_end_function()
+
+    def gen_add_constants_helpers(self, include_base_inertia=False, include_homogenous_transforms=False):
+        n = self.model.n
+        lds = self.lds = self.gen_lds_layout()
+        G = self.lanes_per_solve
+        max_groups = self.suggested_threads // G
+        count = max_groups * lds["TOTAL"]
+        dva_cols, df_cols = self.gen_topology_sparsity_helpers_python()
+        self.gen_add_code_lines(["const int NUM_JOINTS = " + str(n) + ";",
+                                 "const int NUM_VEL = " + str(n) + ";",
+                                 "const int NUM_EES = " + str(sum(1 for c in self.model.children if not c)) + ";",
+                                 "// lane-group decomposition: GRID_LANES_PER_SOLVE consecutive lanes of one wavefront own one solve",
+                                 "const int GRID_LANES_PER_SOLVE = " + str(G) + ";",
+                                 "const int GRID_MAX_THREADS = " + str(self.max_threads) + "; // __launch_bounds__ of every kernel",
+                                 "const int SUGGESTED_THREADS = " + str(self.suggested_threads) + ";",
+                                 "const int GRID_MAX_SOLVES_PER_BLOCK = SUGGESTED_THREADS/GRID_LANES_PER_SOLVE; // what the *_DYNAMIC_SHARED_MEM_COUNT constants cover",
+                                 "// per-solve LDS slice (elements of T) and the offsets of its parts",
+                                 "const int GRID_LDS_PER_SOLVE = " + str(lds["TOTAL"]) + ";"])
+        for k in ("IN", "X", "U", "T", "MINV", "QDD", "OUT"):
+            self.gen_add_code_line("const int GRID_OFF_" + k + " = " + str(lds[k]) + ";")
+        for k in ("ID", "MINV", "FD", "ID_DU", "FD_DU"):
+            self.gen_add_code_line("const int " + k + "_DYNAMIC_SHARED_MEM_COUNT = " + str(count) + ";")
+        self.gen_add_code_lines(["const int ID_DU_MAX_SHARED_MEM_COUNT = " + str(count) + ";",
+                                 "const int FD_DU_MAX_SHARED_MEM_COUNT = " + str(count) + ";",
+                                 "// (reference bookkeeping) derivative columns that are structurally non-zero: dv/da " + str(dva_cols) + ", df " + str(df_cols)])
+        self.gen_add_code_line("// Define custom structs")
+        self.gen_add_code_lines(["template <typename T>", "struct robotModel {", "    T *d_XImats;", "    int *d_topology_helpers;", "};"])
+        self.gen_add_code_lines(["template <typename T>", "struct gridData {",
+                                 "    // GPU INPUTS", "    T *d_q_qd_u;", "    T *d_q_qd;", "    T *d_q;",
+                                 "    // CPU INPUTS", "    T *h_q_qd_u;", "    T *h_q_qd;", "    T *h_q;",
+                                 "    // GPU OUTPUTS", "    T *d_c;", "    T *d_Minv;", "    T *d_qdd;", "    T *d_M;", "    T *d_dc_du;", "    T *d_df_du;",
+                                 "    T *d_eePos;", "    T *d_deePos;", "    T *d_d2eePos;", "    T *d_idsva_so;", "    T *d_df2;",
+                                 "    // CPU OUTPUTS", "    T *h_c;", "    T *h_Minv;", "    T *h_qdd;", "    T *h_M;", "    T *h_dc_du;", "    T *h_df_du;",
+                                 "    T *h_eePos;", "    T *h_deePos;", "    T *h_d2eePos;", "    T *h_idsva_so;", "    T *h_df2;",
+                                 "};"])
+
+    def gen_init_gridData(self):
+        dev = [("d_q_qd_u", "3*NUM_JOINTS"), ("d_q_qd", "2*NUM_JOINTS"), ("d_q", "NUM_JOINTS"), ("d_c", "NUM_JOINTS"),
+               ("d_Minv", "NUM_JOINTS*NUM_JOINTS"), ("d_qdd", "NUM_JOINTS"), ("d_dc_du", "NUM_JOINTS*2*NUM_JOINTS"), ("d_df_du", "NUM_JOINTS*2*NUM_JOINTS")]
+        host = [("h_q_qd_u", "3*NUM_JOINTS"), ("h_q_qd", "2*NUM_JOINTS"), ("h_q", "NUM_JOINTS"), ("h_c", "NUM_JOINTS"),
+                ("h_Minv", "NUM_JOINTS*NUM_JOINTS"), ("h_qdd", "NUM_JOINTS"), ("h_dc_du", "NUM_JOINTS*2*NUM_JOINTS"), ("h_df_du", "NUM_JOINTS*2*NUM_JOINTS")]
+        unused = ["d_M", "d_eePos", "d_deePos", "d_d2eePos", "d_idsva_so", "d_df2", "h_M", "h_eePos", "h_deePos", "h_d2eePos", "h_idsva_so", "h_df2"]
+        code = ["gridData<T> *hd_data = (gridData<T> *)malloc(sizeof(gridData<T>));",
+                "// device buffers of the dynamics algorithms"]
+        code += ["gpuErrchk(hipMalloc((void**)&hd_data->" + nm + ", " + sz + "*NUM_TIMESTEPS*sizeof(T)));" for nm, sz in dev]
+        code += ["// pinned host buffers (so the host wrappers' hipMemcpyAsync really is asynchronous)"]
+        code += ["gpuErrchk(hipHostMalloc((void**)&hd_data->" + nm + ", " + sz + "*NUM_TIMESTEPS*sizeof(T), hipHostMallocDefault));" for nm, sz in host]
+        code += ["// buffers of algorithms that this generator does not emit (kinematics, CRBA, second order) stay null"]
+        code += ["hd_data->" + nm + " = nullptr;" for nm in unused]
+        code += ["return hd_data;"]
+        self.gen_add_func_doc("Allocated device and host memory for all computations", [], [], "A pointer to the gridData struct of pointers")
+        self.gen_add_code_line("template <typename T, int NUM_TIMESTEPS>")
+        self.gen_add_code_line("__host__")
+        self.gen_add_code_line("gridData<T> *init_gridData(){", True)
+        self.gen_add_code_lines(code)
+        self.gen_add_end_function()
+        self.gen_add_func_doc("Allocated device and host memory for all computations", [], ["Max number of timesteps in the trajectory"],
+                              "A pointer to the gridData struct of pointers")
+        self.gen_add_code_line("template <typename T>")
+        self.gen_add_code_line("__host__")
+        self.gen_add_code_line("gridData<T> *init_gridData(int NUM_TIMESTEPS){", True)
+        self.gen_add_code_lines(code)
+        self.gen_add_end_function()
+
+    def gen_init_close_grid(self):
+        MAX_STREAMS = 3
+        self.gen_add_func_doc("Initializes streams for host functions",
+                              ["the per-solve LDS slices fit the default dynamic LDS limit, so no kernel attribute needs raising"], [],
+                              "A pointer to the array of streams")
+        self.gen_add_code_line("template <typename T>")
+        self.gen_add_code_line("__host__")
+        self.gen_add_code_line("hipStream_t *init_grid(){", True)
+        self.gen_add_code_lines(["hipStream_t *streams = (hipStream_t *)malloc(" + str(MAX_STREAMS) + "*sizeof(hipStream_t));",
+                                 "int priority, minPriority, maxPriority;",
+                                 "gpuErrchk(hipDeviceGetStreamPriorityRange(&minPriority, &maxPriority));",
+                                 "for(int i=0; i<" + str(MAX_STREAMS) + "; i++){",
+                                 "    int adjusted_max = maxPriority - i; priority = adjusted_max > minPriority ? adjusted_max : minPriority;",
+                                 "    gpuErrchk(hipStreamCreateWithPriority(&(streams[i]),hipStreamNonBlocking,priority));",
+                                 "}", "return streams;"])
+        self.gen_add_end_function()
+        self.gen_add_func_doc("Frees the memory used by grid", [],
+                              ["streams allocated by init_grid", "robotModel allocated by init_robotModel", "data allocated by init_gridData"], None)
+        self.gen_add_code_line("template <typename T>")
+        self.gen_add_code_line("__host__")
+        self.gen_add_code_line("void close_grid(hipStream_t *streams, robotModel<T> *d_robotModel, gridData<T> *hd_data){", True)
+        self.gen_add_code_lines(["robotModel<T> h_robotModel; gpuErrchk(hipMemcpy(&h_robotModel,d_robotModel,sizeof(robotModel<T>),hipMemcpyDeviceToHost));",
+                                 "gpuErrchk(hipFree(h_robotModel.d_XImats)); gpuErrchk(hipFree(h_robotModel.d_topology_helpers)); gpuErrchk(hipFree(d_robotModel));",
+                                 "gpuErrchk(hipFree(hd_data->d_q_qd_u)); gpuErrchk(hipFree(hd_data->d_q_qd)); gpuErrchk(hipFree(hd_data->d_q));",
+                                 "gpuErrchk(hipFree(hd_data->d_c)); gpuErrchk(hipFree(hd_data->d_Minv)); gpuErrchk(hipFree(hd_data->d_qdd));",
+                                 "gpuErrchk(hipFree(hd_data->d_dc_du)); gpuErrchk(hipFree(hd_data->d_df_du));",
+                                 "gpuErrchk(hipHostFree(hd_data->h_q_qd_u)); gpuErrchk(hipHostFree(hd_data->h_q_qd)); gpuErrchk(hipHostFree(hd_data->h_q));",
+                                 "gpuErrchk(hipHostFree(hd_data->h_c)); gpuErrchk(hipHostFree(hd_data->h_Minv)); gpuErrchk(hipHostFree(hd_data->h_qdd));",
+                                 "gpuErrchk(hipHostFree(hd_data->h_dc_du)); gpuErrchk(hipHostFree(hd_data->h_df_du));",
+                                 "free(hd_data);",
+                                 "for(int i=0; i<" + str(MAX_STREAMS) + "; i++){gpuErrchk(hipStreamDestroy(streams[i]));} free(streams);"])
+        self.gen_add_end_function()
+
+    # ------------------------------------------------------------------ everything
+    def gen_all_code(self, use_thread_group=False, include_base_inertia=False, include_homogenous_transforms=False, fixed_target_name=""):
+        if use_thread_group:
+            raise NotImplementedError("cooperative-groups mode is unfinished in the reference (cgrps::thread_group tgrp = TBD) and has no HIP counterpart here")
+        self.code_str = ""
+        self.indent_level = 0
+        n = self.model.n
+        file_notes = ["Interface is:",
+                      "    __host__   robotModel<T> *d_robotModel = init_robotModel<T>()",
+                      "    __host__   hipStream_t *streams = init_grid<T>()",
+                      "    __host__   gridData<T> *hd_data = init_gridData<T,NUM_TIMESTEPS>();  (or init_gridData<T>(NUM_TIMESTEPS))",
+                      "    __host__   close_grid<T>(hipStream_t *streams, robotModel<T> *d_robotModel, gridData<T> *hd_data)",
+                      "",
+                      "    __device__ inverse_dynamics_inner<T>(T (&c)[NUM_JOINTS], const T *s_qd, [const T *s_qdd,] const T *s_X, const T gravity)",
+                      "    __global__ inverse_dynamics_kernel<T>(T *d_c, const T *d_q_qd, const int stride_q_qd, [const T *d_qdd,] const robotModel<T> *d_robotModel, const T gravity, const int NUM_TIMESTEPS)",
+                      "    __host__   inverse_dynamics<T,USE_QDD_FLAG=false,USE_COMPRESSED_MEM=false>(gridData<T> *hd_data, const robotModel<T> *d_robotModel, const T gravity, const int num_timesteps, const dim3 block_dimms, const dim3 thread_dimms, hipStream_t *streams)",
+                      "",
+                      "    __device__ direct_minv_inner<T>(T *s_Minv, const T *s_X, T *s_U, T *s_T, const robotModel<T> *d_robotModel, const int lane)",
+                      "    __global__ direct_minv_kernel<T>(T *d_Minv, const T *d_q, const int stride_q, const robotModel<T> *d_robotModel, const int NUM_TIMESTEPS)",
+                      "    __host__   direct_minv<T,USE_COMPRESSED_MEM=false>(gridData<T> *hd_data, const robotModel<T> *d_robotModel, const int num_timesteps, const dim3 block_dimms, const dim3 thread_dimms, hipStream_t *streams)",
+                      "",
+                      "    __device__ forward_dynamics_inner<T>(T *s_qdd, const T *s_qd, const T *s_u, const T *s_X, T *s_U, T *s_T, T *s_Minv, const robotModel<T> *d_robotModel, const T gravity, const int lane)",
+                      "    __global__ forward_dynamics_kernel<T>(T *d_qdd, const T *d_q_qd_u, const int stride_q_qd_u, const robotModel<T> *d_robotModel, const T gravity, const int NUM_TIMESTEPS)",
+                      "    __host__   forward_dynamics<T>(gridData<T> *hd_data, const robotModel<T> *d_robotModel, const T gravity, const int num_timesteps, const dim3 block_dimms, const dim3 thread_dimms, hipStream_t *streams)",
+                      "",
+                      "    __device__ inverse_dynamics_gradient_inner<T>(T (&dc_dq)[NUM_JOINTS], T (&dc_dqd)[NUM_JOINTS], const T *s_qd, const T *s_qdd, const T *s_X, const T gravity, const int lane)",
+                      "    __global__ inverse_dynamics_gradient_kernel<T>(T *d_dc_du, const T *d_q_qd, const int stride_q_qd, [const T *d_qdd,] const robotModel<T> *d_robotModel, const T gravity, const int NUM_TIMESTEPS)",
+                      "    __host__   inverse_dynamics_gradient<T,USE_QDD_FLAG=false,USE_COMPRESSED_MEM=false>(gridData<T> *hd_data, const robotModel<T> *d_robotModel, const T gravity, const int num_timesteps, const dim3 block_dimms, const dim3 thread_dimms, hipStream_t *streams)",
+                      "",
+                      "    __device__ forward_dynamics_gradient_device<T>(T *s_df_du, const T *s_q, const T *s_qd, const T *s_u, T *s_work, const robotModel<T> *d_robotModel, const T gravity, const int lane)",
+                      "    __device__ forward_dynamics_gradient_device<T>(T *s_df_du, const T *s_q, const T *s_qd, const T *s_qdd, const T *s_Minv, T *s_work, const robotModel<T> *d_robotModel, const T gravity, const int lane)",
+                      "    __global__ forward_dynamics_gradient_kernel<T>(T *d_df_du, const T *d_q_qd_u, const int stride_q_qd_u, const robotModel<T> *d_robotModel, const T gravity, const int NUM_TIMESTEPS)",
+                      "    __global__ forward_dynamics_gradient_kernel<T>(T *d_df_du, const T *d_q_qd, const int stride_q_qd, const T *d_qdd, const T *d_Minv, const robotModel<T> *d_robotModel, const T gravity, const int NUM_TIMESTEPS)",
+                      "    __host__   forward_dynamics_gradient<T,USE_QDD_MINV_FLAG=false>(gridData<T> *hd_data, const robotModel<T> *d_robotModel, const T gravity, const int num_timesteps, const dim3 block_dimms, const dim3 thread_dimms, hipStream_t *streams)",
+                      "",
+                      "Every host function also exists as NAME_single_timing and NAME_compute_only (no streams argument).",
+                      "",
+                      "Execution model (differs from the CUDA original by design): a lane group of GRID_LANES_PER_SOLVE = " + str(self.lanes_per_solve) + " consecutive lanes of one",
+                      "wavefront owns a solve (lane j <-> joint j), a block of T threads therefore advances T/GRID_LANES_PER_SOLVE solves at a time and",
+                      "grid-strides over the batch.  Launch with thread_dimms <= SUGGESTED_THREADS (" + str(self.suggested_threads) + ") threads and <FUNC_CODE>_DYNAMIC_SHARED_MEM_COUNT*sizeof(T)",
+                      "bytes of dynamic LDS; a natural grid is ceil(num_timesteps*GRID_LANES_PER_SOLVE/threads) blocks.",
+                      "", "Suggested Type T is float"]
+        self.gen_add_func_doc("This instance of grid.cuh (HIP, gfx950) is optimized for the urdf: " + str(self.model.name), file_notes)
+        self.gen_add_code_line("#pragma once")
+        self.gen_add_includes(use_thread_group)
+        self.gen_add_gpu_err()
+        self.gen_add_code_line("// dynamic LDS of the block; every kernel carves one GRID_LDS_PER_SOLVE slice per lane group out of it")
+        self.gen_add_code_line("extern __shared__ unsigned char grid_smem_raw[];")
+        self.gen_add_code_line("")
+        self.gen_add_func_doc("All functions are kept in this namespace")
+        self.gen_add_code_line("namespace " + self.file_namespace + " {", True)
+        self.gen_add_constants_helpers(include_base_inertia, include_homogenous_transforms)
+        self.gen_spatial_algebra_helpers()
+        self.gen_init_topology_helpers()
+        self.gen_init_XImats(include_base_inertia, include_homogenous_transforms)
+        self.gen_init_robotModel()
+        self.gen_init_gridData()
+        self.gen_load_update_XImats_helpers(use_thread_group)
+        # the dynamics algorithms on (and next to) the forward-dynamics-gradient path
+        self.gen_inverse_dynamics(use_thread_group)
+        self.gen_direct_minv(use_thread_group)
+        self.gen_forward_dynamics(use_thread_group)
+        self.gen_inverse_dynamics_gradient(use_thread_group)
+        self.gen_forward_dynamics_gradient(use_thread_group)
+        self.gen_init_close_grid()
+        self.gen_add_end_control_flow()
+        with open(self.file_namespace + ".cuh", "w") as f:
+            f.write(self.code_str)
+        return self.code_str

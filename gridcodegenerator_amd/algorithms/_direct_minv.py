@@ -1,0 +1,214 @@
+"""Analytical inverse of the joint-space inertia matrix, emitter for the HIP/CDNA4 backend.
+
+Mirrors the role of the reference's algorithms/_direct_minv.py (gen_direct_minv_inner :23-453, device :455,
+kernel :478, host :527) and follows the reference oracle /root/reference/_test.py:117-226
+(test_minv_bpass / test_minv_fpass / test_densify_Minv; Carpentier's analytical M^-1).
+
+Lane mapping (lane j of the solve's lane group):
+  * owns COLUMN j of M^-1 (register vector Mcol[i] = Minv[i][j]) and the matching column of every F_i;
+    F_i[:,j] is zero unless j is in subtree(i), so zeros propagate structurally and no masks are needed
+    (for the oracle's subtree index sets, _test.py:151-168);
+  * lanes 0..5 additionally own COLUMN j of every articulated inertia IA_i.  The two-sided update
+    IA_p += X^T (IA - U D^-1 U^T) X is done as two one-sided "X^T * 6-vector" products with a 6x6 transpose
+    through LDS in between (R[:,c] = X^T (X^T Ia)[c,:]^T, valid because Ia is symmetric), i.e. 2x27 FMAs per
+    lane instead of ~324 on one thread;
+  * U_i = IA_i[:, S_i] is published through LDS by the lane that owns that column.
+The forward sweep (serial over joints in the reference, :371-452) becomes a pre-order walk where each lane
+carries its own column of F.
+"""
+
+
+def gen_direct_minv_inner_temp_mem_size(self):
+    return 0  # LDS needs are part of the fixed per-solve slice (helpers/_topology_helpers.py: gen_lds_layout)
+
+
+def gen_direct_minv_inner_function_call(self, use_thread_group=False, updated_var_names=None):
+    self.gen_add_code_line("direct_minv_inner<T>(s_Minv, s_X, s_U, s_T, d_robotModel, lane);")
+    self.gen_add_sync(use_thread_group)
+
+
+def gen_direct_minv_inner(self, use_thread_group=False):
+    m = self.model
+    n = m.n
+    self.gen_add_func_doc("Compute the inverse of the mass matrix (dense, symmetric) into LDS",
+                          ["follows /root/reference/_test.py:117-226; lane j produces column j (and, by symmetry, row j)",
+                           "the caller must grid_wave_sync() before other lanes' entries of s_Minv are read"],
+                          ["s_Minv is the n x n output in LDS (symmetric, so row- and column-major coincide)",
+                           "s_X is this solve's compact X(q) storage", "s_U is LDS scratch: per joint U (6), 1/D, pad",
+                           "s_T is LDS scratch for the 6x6 transpose (row stride 8)",
+                           "d_robotModel is the pointer to the initialized model specific helpers on the GPU",
+                           "lane is the caller's lane index inside the solve's lane group"], None)
+    self.gen_add_code_line("template <typename T>")
+    self.gen_add_code_line("__device__ __forceinline__")
+    self.gen_add_code_line("void direct_minv_inner(T *s_Minv, const T *s_X, T *s_U, T *s_T, const robotModel<T> *d_robotModel, const int lane) {", True)
+    self.gen_add_code_line("const int cI = lane < 5 ? lane : 5; // articulated-inertia column owned by this lane (lanes 0..5 are live)")
+    self.gen_add_code_line("const T *d_I = &d_robotModel->d_XImats[" + str(18 * n) + " + 6*cI];")
+    self.gen_add_code_line("T Mcol[" + str(n) + "];")
+    self.gen_add_code_line("//")
+    self.gen_add_code_line("// backward sweep (post-order): U, D^-1, Minv row updates, F and IA propagation to the parent")
+    self.gen_add_code_line("//")
+
+    def pre_b(i):
+        self.gen_add_code_line("T IA_%d[6], F_%d[6];" % (i, i))
+        self.gen_add_code_line("#pragma unroll")
+        self.gen_add_code_line("for (int r = 0; r < 6; r++) { IA_%d[r] = d_I[%d + r]; F_%d[r] = static_cast<T>(0); }" % (i, 36 * i, i))
+
+    def post_b(i):
+        s, p = m.S_index[i], m.parent[i]
+        self.gen_add_code_line("if (lane == %d) {" % s, True)
+        self.gen_add_code_line("#pragma unroll")
+        self.gen_add_code_line("for (int r = 0; r < 6; r++) { s_U[%d + r] = IA_%d[r]; }" % (8 * i, i))
+        self.gen_add_end_control_flow()
+        self.gen_add_sync(use_thread_group)
+        self.gen_add_code_line("{", True)
+        self.gen_add_code_line("T U[6];")
+        self.gen_add_code_line("#pragma unroll")
+        self.gen_add_code_line("for (int r = 0; r < 6; r++) { U[r] = s_U[%d + r]; }" % (8 * i))
+        self.gen_add_code_line("const T Dinv = static_cast<T>(1)/U[%d];" % s)
+        self.gen_add_code_line("if (lane == 0) { s_U[%d] = Dinv; }" % (8 * i + 6))
+        self.gen_add_code_line("const T m = ((lane == %d) ? Dinv : static_cast<T>(0)) - Dinv*F_%d[%d];" % (i, i, s))
+        self.gen_add_code_line("Mcol[%d] = m;" % i)
+        if p != -1:
+            self.gen_add_code_line("T X[18]; grid_load_X(X, &s_X[GRID_X_STRIDE*%d]);" % i)
+            self.gen_add_code_line("#pragma unroll")
+            self.gen_add_code_line("for (int r = 0; r < 6; r++) { F_%d[r] += U[r]*m; }" % i)
+            self.gen_add_code_line("grid_xtmul_peq(F_%d, X, F_%d);" % (p, i))
+            self.gen_add_code_line("// IA_parent += X^T (IA - U Dinv U^T) X, one column per lane, transposed through LDS")
+            self.gen_add_code_line("T Ia[6], Tc[6], Tr[6];")
+            self.gen_add_code_line("const T w = Dinv*IA_%d[%d];" % (i, s))
+            self.gen_add_code_line("#pragma unroll")
+            self.gen_add_code_line("for (int r = 0; r < 6; r++) { Ia[r] = IA_%d[r] - U[r]*w; }" % i)
+            self.gen_add_code_line("grid_xtmul(Tc, X, Ia);")
+            self.gen_add_code_line("if (lane < 6) {", True)
+            self.gen_add_code_line("#pragma unroll")
+            self.gen_add_code_line("for (int r = 0; r < 6; r++) { s_T[8*r + lane] = Tc[r]; }")
+            self.gen_add_end_control_flow()
+            self.gen_add_sync(use_thread_group)
+            self.gen_add_code_line("#pragma unroll")
+            self.gen_add_code_line("for (int r = 0; r < 6; r++) { Tr[r] = s_T[8*cI + r]; }")
+            self.gen_add_code_line("grid_xtmul_peq(IA_%d, X, Tr);" % p)
+            self.gen_add_sync(use_thread_group)
+        self.gen_add_end_control_flow()
+
+    self.gen_tree_traversal(pre_b, post_b)
+    self.gen_add_sync(use_thread_group)
+    self.gen_add_code_line("//")
+    self.gen_add_code_line("// forward sweep (pre-order): Minv[i,j] -= Dinv_i U_i^T (X_i F_parent[:,j]);  F_i[:,j] = S_i Minv[i,j] + X_i F_parent[:,j]")
+    self.gen_add_code_line("// (entries with j < i are scratch: only the upper triangle is defined, the store below mirrors it)")
+    self.gen_add_code_line("//")
+
+    def pre_f(i):
+        s, p = m.S_index[i], m.parent[i]
+        has_children = len(m.children[i]) > 0
+        if p == -1:
+            if has_children:
+                self.gen_add_code_line("T Ff_%d[6]; grid_zero6(Ff_%d); Ff_%d[%d] = Mcol[%d];" % (i, i, i, s, i))
+            return
+        self.gen_add_code_line("T Ff_%d[6];" % i)
+        self.gen_add_code_line("{", True)
+        self.gen_add_code_line("T X[18]; grid_load_X(X, &s_X[GRID_X_STRIDE*%d]);" % i)
+        self.gen_add_code_line("T U[6];")
+        self.gen_add_code_line("#pragma unroll")
+        self.gen_add_code_line("for (int r = 0; r < 6; r++) { U[r] = s_U[%d + r]; }" % (8 * i))
+        self.gen_add_code_line("grid_xmul(Ff_%d, X, Ff_%d);" % (i, p))
+        self.gen_add_code_line("Mcol[%d] -= s_U[%d]*grid_dot6(U, Ff_%d);" % (i, 8 * i + 6, i))
+        if has_children:
+            self.gen_add_code_line("Ff_%d[%d] += Mcol[%d];" % (i, s, i))
+        self.gen_add_end_control_flow()
+
+    def post_f(i):
+        pass
+
+    self.gen_tree_traversal(pre_f, post_f)
+    self.gen_add_code_line("// publish: lane j writes the upper-triangle entries of its column and their mirror images")
+    self.gen_add_code_line("if (lane < %d) {" % n, True)
+    for i in range(n):
+        self.gen_add_code_line("if (lane >= %d) { s_Minv[%d + lane] = Mcol[%d]; s_Minv[lane*%d + %d] = Mcol[%d]; }" % (i, i * n, i, n, i, i))
+    self.gen_add_end_control_flow()
+    self.gen_add_end_function()
+
+
+def gen_direct_minv_kernel(self, use_thread_group=False, single_call_timing=False):
+    n = self.model.n
+    func_params = ["d_Minv is the output: upper triangle of M^-1, column-major (d_Minv[k*n*n + col*n + row], entries below the diagonal are 0)",
+                   "d_q is the vector of joint positions", "stride_q is the stride between each q",
+                   "d_robotModel is the pointer to the initialized model specific helpers on the GPU (XImats, topology_helpers, etc.)",
+                   "num_timesteps is the length of the trajectory points we need to compute over (or overloaded as test_iters for timing)"]
+    func_def = "void direct_minv_kernel(T *d_Minv, const T *d_q, const int stride_q, const robotModel<T> *d_robotModel, const int NUM_TIMESTEPS) {"
+    if single_call_timing:
+        func_def = func_def.replace("kernel(", "kernel_single_timing(")
+    self.gen_add_func_doc("Compute the inverse of the mass matrix", ["Outputs a SYMMETRIC_UPPER triangular matrix for Minv (as the reference does)"], func_params, None)
+    self.gen_add_code_line("template <typename T>")
+    self.gen_add_code_line("__global__ __launch_bounds__(GRID_MAX_THREADS)")
+    self.gen_add_code_line(func_def, True)
+    self.gen_kernel_prologue("GRID_LDS_PER_SOLVE")
+    self.gen_add_code_lines(["T *s_q = &s_mem[GRID_OFF_IN];",
+                             "T *s_X = &s_mem[GRID_OFF_X]; T *s_U = &s_mem[GRID_OFF_U]; T *s_T = &s_mem[GRID_OFF_T]; T *s_Minv = &s_mem[GRID_OFF_MINV]; T *s_out = &s_mem[GRID_OFF_OUT];"])
+    if single_call_timing:
+        self.gen_add_code_line("const int k = 0; const int kc = 0; const bool valid = (blockIdx.x + blockIdx.y == 0) && (grp == 0);")
+        self.gen_add_code_line("if (!valid) {return;}")
+    else:
+        self.gen_add_parallel_loop("k", "NUM_TIMESTEPS", use_thread_group, block_level=True)
+    self.gen_kernel_load_inputs("q", "stride_q", n, use_thread_group)
+    if single_call_timing:
+        self.gen_add_code_line("for (int rep = 0; rep < NUM_TIMESTEPS; rep++){", True)
+    self.gen_add_code_line("// compute")
+    self.gen_load_update_XImats_helpers_function_call(use_thread_group)
+    self.gen_direct_minv_inner_function_call(use_thread_group)
+    if single_call_timing:
+        self.gen_add_end_control_flow()
+    self.gen_add_code_line("// upper triangle only in the output record")
+    self.gen_add_parallel_loop("ind", str(n * n), use_thread_group)
+    self.gen_add_code_line("const int row = ind %% %d; const int col = ind / %d;" % (n, n))
+    self.gen_add_code_line("s_out[ind] = (row <= col) ? s_Minv[ind] : static_cast<T>(0);")
+    self.gen_add_end_control_flow()
+    self.gen_kernel_save_result("Minv", n * n, n * n, use_thread_group, "s_out")
+    if not single_call_timing:
+        self.gen_add_end_control_flow()
+    self.gen_add_end_function()
+
+
+def gen_direct_minv_host(self, mode=0):
+    single_call_timing = mode == 1
+    compute_only = mode == 2
+    func_params = ["hd_data is the packaged input and output pointers",
+                   "d_robotModel is the pointer to the initialized model specific helpers on the GPU (XImats, topology_helpers, etc.)",
+                   "num_timesteps is the length of the trajectory points we need to compute over (or overloaded as test_iters for timing)",
+                   "streams are pointers to HIP streams for async memory transfers (if needed)"]
+    name = "direct_minv" + ("_single_timing" if single_call_timing else "") + ("_compute_only" if compute_only else "")
+    self.gen_add_func_doc("Compute the inverse of the mass matrix", [], func_params, None)
+    self.gen_add_code_line("template <typename T, bool USE_COMPRESSED_MEM = false>")
+    self.gen_add_code_line("__host__")
+    self.gen_add_code_line("void " + name + "(gridData<T> *hd_data, const robotModel<T> *d_robotModel, const int num_timesteps,")
+    self.gen_add_code_line("                      const dim3 block_dimms, const dim3 thread_dimms" + ("" if compute_only else ", hipStream_t *streams") + ") {", True)
+    self.gen_add_code_line("int stride_q = USE_COMPRESSED_MEM ? NUM_JOINTS: 3*NUM_JOINTS;")
+    cnt = "" if single_call_timing else "num_timesteps*"
+    if not compute_only:
+        self.gen_add_code_lines(["// start code with memory transfer",
+                                 "if (USE_COMPRESSED_MEM) {gpuErrchk(hipMemcpyAsync(hd_data->d_q,hd_data->h_q,stride_q*" + cnt + "sizeof(T),hipMemcpyHostToDevice,streams[0]));}",
+                                 "else {gpuErrchk(hipMemcpyAsync(hd_data->d_q_qd_u,hd_data->h_q_qd_u,stride_q*" + cnt + "sizeof(T),hipMemcpyHostToDevice,streams[0]));}",
+                                 "gpuErrchk(hipDeviceSynchronize());"])
+    kern = "direct_minv_kernel" + ("_single_timing" if single_call_timing else "") + "<T>"
+    self.gen_add_code_line("// then call the kernel")
+    self.gen_add_code_line("const T *d_in = USE_COMPRESSED_MEM ? hd_data->d_q : hd_data->d_q_qd_u;")
+    if single_call_timing:
+        self.gen_add_code_line("struct timespec start, end; clock_gettime(CLOCK_MONOTONIC,&start);")
+    self.gen_add_code_lines(["hipLaunchKernelGGL((" + kern + "),block_dimms,thread_dimms,MINV_DYNAMIC_SHARED_MEM_COUNT*sizeof(T),0,hd_data->d_Minv,d_in,stride_q,d_robotModel,num_timesteps);",
+                             "gpuErrchk(hipGetLastError()); gpuErrchk(hipDeviceSynchronize());"])
+    if single_call_timing:
+        self.gen_add_code_line("clock_gettime(CLOCK_MONOTONIC,&end);")
+    if not compute_only:
+        self.gen_add_code_lines(["// finally transfer the result back",
+                                 "gpuErrchk(hipMemcpy(hd_data->h_Minv,hd_data->d_Minv,NUM_JOINTS*NUM_JOINTS*" + cnt + "sizeof(T),hipMemcpyDeviceToHost));",
+                                 "gpuErrchk(hipDeviceSynchronize());"])
+    if single_call_timing:
+        self.gen_add_code_line("printf(\"Single Call Minv %fus\\n\",time_delta_us_timespec(start,end)/static_cast<double>(num_timesteps));")
+    self.gen_add_end_function()
+
+
+def gen_direct_minv(self, use_thread_group=False):
+    self.gen_direct_minv_inner(use_thread_group)
+    self.gen_direct_minv_kernel(use_thread_group, True)
+    self.gen_direct_minv_kernel(use_thread_group, False)
+    for mode in (0, 1, 2):
+        self.gen_direct_minv_host(mode)

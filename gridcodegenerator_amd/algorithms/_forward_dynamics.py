@@ -1,0 +1,137 @@
+"""Forward dynamics emitter for the HIP/CDNA4 backend: qdd = M^-1 (u - c).
+
+Mirrors the role of the reference's algorithms/_forward_dynamics.py (gen_forward_dynamics_finish :21-50,
+gen_forward_dynamics_inner :73, device/kernel/host :110-255); mathematics as in /root/reference/_test.py:498-501.
+"""
+
+
+def gen_forward_dynamics_inner_temp_mem_size(self):
+    return 0
+
+
+def gen_forward_dynamics_finish_function_call(self, use_thread_group=False, updated_var_names=None):
+    self.gen_add_code_line("forward_dynamics_finish<T>(s_qdd, s_u, c, s_Minv, lane);")
+    self.gen_add_sync(use_thread_group)
+
+
+def gen_forward_dynamics_finish(self, use_thread_group=False):
+    n = self.model.n
+    self.gen_add_func_doc("Finish the forward dynamics computation with qdd = Minv*(u-c)",
+                          ["lane r computes qdd[r]; s_Minv is dense symmetric so no upper-triangle index trick is needed",
+                           "the caller must grid_wave_sync() before s_qdd is read by other lanes"],
+                          ["s_qdd is a pointer to LDS for the final result", "s_u is the vector of joint input torques in LDS",
+                           "c is the bias force (registers, identical in every lane)", "s_Minv is the (dense symmetric) inverse mass matrix in LDS",
+                           "lane is the caller's lane index inside the solve's lane group"], None)
+    self.gen_add_code_line("template <typename T>")
+    self.gen_add_code_line("__device__ __forceinline__")
+    self.gen_add_code_line("void forward_dynamics_finish(T *s_qdd, const T *s_u, const T (&c)[%d], const T *s_Minv, const int lane) {" % n, True)
+    self.gen_add_code_line("if (lane < %d) {" % n, True)
+    self.gen_add_code_line("T val = static_cast<T>(0);")
+    self.gen_add_code_line("#pragma unroll")
+    self.gen_add_code_line("for (int col = 0; col < %d; col++) { val += s_Minv[lane*%d + col]*(s_u[col] - c[col]); }" % (n, n))
+    self.gen_add_code_line("s_qdd[lane] = val;")
+    self.gen_add_end_control_flow()
+    self.gen_add_end_function()
+
+
+def gen_forward_dynamics_inner_function_call(self, use_thread_group=False, updated_var_names=None):
+    self.gen_add_code_line("forward_dynamics_inner<T>(s_qdd, s_qd, s_u, s_X, s_U, s_T, s_Minv, d_robotModel, gravity, lane);")
+
+
+def gen_forward_dynamics_inner(self, use_thread_group=False):
+    n = self.model.n
+    self.gen_add_func_doc("Computes forward dynamics", ["direct_minv_inner + inverse_dynamics_inner(qdd = 0) + forward_dynamics_finish; s_qdd and s_Minv are valid for all lanes on return"],
+                          ["s_qdd is a pointer to LDS for the final result", "s_qd is the vector of joint velocities", "s_u is the vector of joint input torques",
+                           "s_X is this solve's compact X(q) storage", "s_U, s_T are LDS scratch (see direct_minv_inner)", "s_Minv receives the dense inverse mass matrix",
+                           "d_robotModel is the pointer to the initialized model specific helpers on the GPU", "gravity is the gravity constant",
+                           "lane is the caller's lane index inside the solve's lane group"], None)
+    self.gen_add_code_line("template <typename T>")
+    self.gen_add_code_line("__device__ __forceinline__")
+    self.gen_add_code_line("void forward_dynamics_inner(T *s_qdd, const T *s_qd, const T *s_u, const T *s_X, T *s_U, T *s_T, T *s_Minv, const robotModel<T> *d_robotModel, const T gravity, const int lane) {", True)
+    self.gen_direct_minv_inner_function_call(use_thread_group)
+    self.gen_add_code_line("T c[%d];" % n)
+    self.gen_inverse_dynamics_inner_function_call(use_thread_group, True, False)
+    self.gen_forward_dynamics_finish_function_call(use_thread_group)
+    self.gen_add_end_function()
+
+
+def gen_forward_dynamics_kernel(self, use_thread_group=False, single_call_timing=False):
+    n = self.model.n
+    func_params = ["d_qdd is the vector of joint accelerations", "d_q_qd_u is the vector of joint positions, velocities, and input torques",
+                   "stride_q_qd_u is the stride between each q, qd, u",
+                   "d_robotModel is the pointer to the initialized model specific helpers on the GPU (XImats, topology_helpers, etc.)",
+                   "gravity is the gravity constant",
+                   "num_timesteps is the length of the trajectory points we need to compute over (or overloaded as test_iters for timing)"]
+    func_def = "void forward_dynamics_kernel(T *d_qdd, const T *d_q_qd_u, const int stride_q_qd_u, const robotModel<T> *d_robotModel, const T gravity, const int NUM_TIMESTEPS) {"
+    if single_call_timing:
+        func_def = func_def.replace("kernel(", "kernel_single_timing(")
+    self.gen_add_func_doc("Computes forward dynamics", [], func_params, None)
+    self.gen_add_code_line("template <typename T>")
+    self.gen_add_code_line("__global__ __launch_bounds__(GRID_MAX_THREADS)")
+    self.gen_add_code_line(func_def, True)
+    self.gen_kernel_prologue("GRID_LDS_PER_SOLVE")
+    self.gen_add_code_lines(["T *s_q_qd_u = &s_mem[GRID_OFF_IN]; T *s_q = s_q_qd_u; T *s_qd = &s_q_qd_u[%d]; T *s_u = &s_q_qd_u[%d];" % (n, 2 * n),
+                             "T *s_X = &s_mem[GRID_OFF_X]; T *s_U = &s_mem[GRID_OFF_U]; T *s_T = &s_mem[GRID_OFF_T]; T *s_Minv = &s_mem[GRID_OFF_MINV]; T *s_qdd = &s_mem[GRID_OFF_QDD];"])
+    if single_call_timing:
+        self.gen_add_code_line("const int k = 0; const int kc = 0; const bool valid = (blockIdx.x + blockIdx.y == 0) && (grp == 0);")
+        self.gen_add_code_line("if (!valid) {return;}")
+    else:
+        self.gen_add_parallel_loop("k", "NUM_TIMESTEPS", use_thread_group, block_level=True)
+    self.gen_kernel_load_inputs("q_qd_u", "stride_q_qd_u", 3 * n, use_thread_group)
+    if single_call_timing:
+        self.gen_add_code_line("for (int rep = 0; rep < NUM_TIMESTEPS; rep++){", True)
+    self.gen_add_code_line("// compute")
+    self.gen_load_update_XImats_helpers_function_call(use_thread_group)
+    self.gen_forward_dynamics_inner_function_call(use_thread_group)
+    if single_call_timing:
+        self.gen_add_end_control_flow()
+    self.gen_kernel_save_result("qdd", n, n, use_thread_group)
+    if not single_call_timing:
+        self.gen_add_end_control_flow()
+    self.gen_add_end_function()
+
+
+def gen_forward_dynamics_host(self, mode=0):
+    single_call_timing = mode == 1
+    compute_only = mode == 2
+    func_params = ["hd_data is the packaged input and output pointers",
+                   "d_robotModel is the pointer to the initialized model specific helpers on the GPU (XImats, topology_helpers, etc.)",
+                   "gravity is the gravity constant,",
+                   "num_timesteps is the length of the trajectory points we need to compute over (or overloaded as test_iters for timing)",
+                   "streams are pointers to HIP streams for async memory transfers (if needed)"]
+    name = "forward_dynamics" + ("_single_timing" if single_call_timing else "") + ("_compute_only" if compute_only else "")
+    self.gen_add_func_doc("Computes forward dynamics", [], func_params, None)
+    self.gen_add_code_line("template <typename T>")
+    self.gen_add_code_line("__host__")
+    self.gen_add_code_line("void " + name + "(gridData<T> *hd_data, const robotModel<T> *d_robotModel, const T gravity, const int num_timesteps,")
+    self.gen_add_code_line("                      const dim3 block_dimms, const dim3 thread_dimms" + ("" if compute_only else ", hipStream_t *streams") + ") {", True)
+    self.gen_add_code_line("int stride_q_qd_u = 3*NUM_JOINTS;")
+    cnt = "" if single_call_timing else "num_timesteps*"
+    if not compute_only:
+        self.gen_add_code_lines(["// start code with memory transfer",
+                                 "gpuErrchk(hipMemcpyAsync(hd_data->d_q_qd_u,hd_data->h_q_qd_u,stride_q_qd_u*" + cnt + "sizeof(T),hipMemcpyHostToDevice,streams[0]));",
+                                 "gpuErrchk(hipDeviceSynchronize());"])
+    kern = "forward_dynamics_kernel" + ("_single_timing" if single_call_timing else "") + "<T>"
+    self.gen_add_code_line("// then call the kernel")
+    if single_call_timing:
+        self.gen_add_code_line("struct timespec start, end; clock_gettime(CLOCK_MONOTONIC,&start);")
+    self.gen_add_code_lines(["hipLaunchKernelGGL((" + kern + "),block_dimms,thread_dimms,FD_DYNAMIC_SHARED_MEM_COUNT*sizeof(T),0,hd_data->d_qdd,hd_data->d_q_qd_u,stride_q_qd_u,d_robotModel,gravity,num_timesteps);",
+                             "gpuErrchk(hipGetLastError()); gpuErrchk(hipDeviceSynchronize());"])
+    if single_call_timing:
+        self.gen_add_code_line("clock_gettime(CLOCK_MONOTONIC,&end);")
+    if not compute_only:
+        self.gen_add_code_lines(["// finally transfer the result back",
+                                 "gpuErrchk(hipMemcpy(hd_data->h_qdd,hd_data->d_qdd,NUM_JOINTS*" + cnt + "sizeof(T),hipMemcpyDeviceToHost));",
+                                 "gpuErrchk(hipDeviceSynchronize());"])
+    if single_call_timing:
+        self.gen_add_code_line("printf(\"Single Call FD %fus\\n\",time_delta_us_timespec(start,end)/static_cast<double>(num_timesteps));")
+    self.gen_add_end_function()
+
+
+def gen_forward_dynamics(self, use_thread_group=False):
+    self.gen_forward_dynamics_finish(use_thread_group)
+    self.gen_forward_dynamics_inner(use_thread_group)
+    self.gen_forward_dynamics_kernel(use_thread_group, True)
+    self.gen_forward_dynamics_kernel(use_thread_group, False)
+    for mode in (0, 1, 2):
+        self.gen_forward_dynamics_host(mode)

@@ -1,0 +1,145 @@
+"""Emission primitives for the HIP/CDNA4 backend.
+
+Replaces the reference's helpers/_code_generation_helpers.py (parallel-loop / sync / select / load-save emitters,
+reference lines 1-199) with wave64-native equivalents.  The execution model these primitives emit is NOT the
+reference's "one block per solve, block-wide strided loops + __syncthreads": here a *lane group* of
+GRID_LANES_PER_SOLVE (8/16/32/64) consecutive lanes of one wavefront owns a solve, lane j owns joint j
+(its X update, its Minv column, its two gradient columns), groups never straddle a wave, and every
+hand-off goes through LDS followed by a wave-level sync (no s_barrier).
+"""
+
+
+def gen_add_code_line(self, new_code_line, add_indent_after=False):
+    self.code_str += self.indent_level * "    " + new_code_line + "\n"
+    if add_indent_after:
+        self.indent_level += 1
+
+
+def gen_add_code_lines(self, new_code_lines, add_indent_after=False):
+    for line in new_code_lines:
+        self.gen_add_code_line(line)
+    if add_indent_after:
+        self.indent_level += 1
+
+
+def gen_add_end_control_flow(self):
+    self.indent_level -= 1
+    self.gen_add_code_line("}")
+
+
+def gen_add_end_function(self):
+    self.indent_level -= 1
+    self.gen_add_code_line("}\n")
+
+
+def gen_add_func_doc(self, func_desc, notes=[], params=[], return_val=None):
+    self.gen_add_code_line("/**")
+    self.gen_add_code_line(" * " + func_desc)
+    self.gen_add_code_line(" *")
+    if len(notes) > 0:
+        self.gen_add_code_line(" * Notes:")
+        for note in notes:
+            self.gen_add_code_line(" *   " + note)
+        self.gen_add_code_line(" *")
+    for param in params:
+        self.gen_add_code_line(" * @param " + param)
+    if return_val is not None:
+        self.gen_add_code_line(" * @return " + return_val)
+    self.gen_add_code_line(" */")
+
+
+def gen_add_serial_ops(self, use_thread_group=False):
+    """One lane of the solve's lane group (reference: thread 0 of the block)."""
+    self.gen_add_code_line("if(lane == 0){", True)
+
+
+def gen_add_parallel_loop(self, var_name, max_val, use_thread_group=False, block_level=False):
+    """block_level: grid-stride loop over *batches* of solves (one solve per lane group, gpb groups per block).
+    otherwise: loop strided over the lanes of this solve's lane group."""
+    if block_level:
+        self.gen_add_code_line("for(int " + var_name + "0 = (blockIdx.x + blockIdx.y*gridDim.x)*gpb; " + var_name + "0 < " + max_val +
+                               "; " + var_name + "0 += gridDim.x*gridDim.y*gpb){", True)
+        self.gen_add_code_line("const int " + var_name + " = " + var_name + "0 + grp; const bool valid = " + var_name + " < " + max_val +
+                               "; const int " + var_name + "c = valid ? " + var_name + " : " + max_val + " - 1;")
+    else:
+        self.gen_add_code_line("for(int " + var_name + " = lane; " + var_name + " < " + max_val + "; " + var_name +
+                               " += GRID_LANES_PER_SOLVE){", True)
+
+
+def gen_add_sync(self, use_thread_group=False):
+    """Wave-level hand-off point: LDS is in-order per wave, so only the compiler needs fencing."""
+    self.gen_add_code_line("grid_wave_sync();")
+
+
+def gen_var_in_list(self, var_name, option_list):
+    if len(option_list) == 1:
+        return "(" + var_name + " == " + option_list[0] + ")"
+    return "(" + " || ".join(["(" + var_name + " == " + o + ")" for o in option_list]) + ")"
+
+
+def gen_var_not_in_list(self, var_name, option_list):
+    if len(option_list) == 1:
+        return "(" + var_name + " != " + option_list[0] + ")"
+    return "(" + " && ".join(["(" + var_name + " != " + o + ")" for o in option_list]) + ")"
+
+
+def gen_lane_mask_test(self, ids, var_name="lane"):
+    """Compile-time lane-set membership as a 64-bit mask test (used for per-joint-type dispatch)."""
+    mask = 0
+    for i in ids:
+        mask |= 1 << i
+    return "((0x%xull >> %s) & 1ull)" % (mask, var_name)
+
+
+def gen_kernel_prologue(self, lds_per_solve_const):
+    """Lane-group decomposition shared by every kernel.  Threads beyond the last whole lane group (or beyond
+    GRID_MAX_SOLVES_PER_BLOCK groups, which is what the *_DYNAMIC_SHARED_MEM_COUNT constants are sized for) retire."""
+    self.gen_add_code_lines([
+        "const int tid = threadIdx.x + threadIdx.y*blockDim.x;",
+        "const int lane = tid & (GRID_LANES_PER_SOLVE-1); // lane j of a solve's lane group owns joint j",
+        "const int grp = tid / GRID_LANES_PER_SOLVE;",
+        "int gpb = (blockDim.x*blockDim.y) / GRID_LANES_PER_SOLVE; if (gpb > GRID_MAX_SOLVES_PER_BLOCK) {gpb = GRID_MAX_SOLVES_PER_BLOCK;}",
+        "if (grp >= gpb) {return;}",
+        "T *s_mem = reinterpret_cast<T *>(grid_smem_raw) + grp*" + lds_per_solve_const + ";",
+    ])
+
+
+def gen_kernel_load_inputs(self, name, stride, amount, use_thread_group=False, name2=None, stride2=1, amount2=1,
+                           name3=None, stride3=1, amount3=1, symmetrize3=None):
+    """global -> this solve's LDS slice.  Consecutive lanes read consecutive floats and consecutive lane groups read
+    consecutive solves, so a wave's loads cover one contiguous span of the AoS input (SURVEY.md 8(a) a1 layout)."""
+    self.gen_add_code_line("// load this solve's inputs to LDS (coalesced across the lane groups of the wave)")
+    for (nm, st, am) in ((name, stride, amount), (name2, stride2, amount2)):
+        if nm is None:
+            continue
+        self.gen_add_code_line("const T *d_" + nm + "_k = &d_" + nm + "[kc*" + str(st) + "];")
+        self.gen_add_parallel_loop("ind", str(am), use_thread_group)
+        self.gen_add_code_line("s_" + nm + "[ind] = d_" + nm + "_k[ind];")
+        self.gen_add_end_control_flow()
+    if name3 is not None:
+        n = symmetrize3
+        self.gen_add_code_line("const T *d_" + name3 + "_k = &d_" + name3 + "[kc*" + str(stride3) + "];")
+        self.gen_add_parallel_loop("ind", str(amount3), use_thread_group)
+        if n is None:
+            self.gen_add_code_line("s_" + name3 + "[ind] = d_" + name3 + "_k[ind];")
+        else:
+            self.gen_add_code_line("// only the upper triangle of the caller's matrix is dereferenced (reference _forward_dynamics_gradient.py:54)")
+            self.gen_add_code_line("const int row = ind % " + str(n) + "; const int col = ind / " + str(n) + ";")
+            self.gen_add_code_line("s_" + name3 + "[ind] = d_" + name3 + "_k[(row <= col) ? (col*" + str(n) + " + row) : (row*" + str(n) + " + col)];")
+        self.gen_add_end_control_flow()
+    self.gen_add_sync(use_thread_group)
+
+
+def gen_kernel_save_result(self, store_to_name, stride, amount, use_thread_group=False, load_from_name=None):
+    """this solve's LDS slice -> global, lanes strided over the contiguous output record."""
+    if load_from_name is None:
+        load_from_name = "s_" + store_to_name
+    self.gen_add_sync(use_thread_group)
+    self.gen_add_code_line("// save down to global")
+    self.gen_add_code_line("if (valid) {", True)
+    self.gen_add_code_line("T *d_" + store_to_name + "_k = &d_" + store_to_name + "[k*" + str(stride) + "];")
+    self.gen_add_parallel_loop("ind", str(amount), use_thread_group)
+    self.gen_add_code_line("d_" + store_to_name + "_k[ind] = " + load_from_name + "[ind];")
+    self.gen_add_end_control_flow()
+    self.gen_add_end_control_flow()
+    self.gen_add_sync(use_thread_group)

@@ -1,0 +1,123 @@
+"""Register-resident 6-vector device functions for the HIP/CDNA4 backend.
+
+Replaces the reference's helpers/_spatial_algebra_helpers.py (dot_prod / mx0..5 / mxX / fx_times_v emitters that
+operate in place on shared memory, reference lines 122-344) with functions on per-lane register 6-vectors
+(``T v[6]`` fully unrolled -> VGPRs).  Every joint transform is applied in its block form
+``X = [[E, 0], [B, E]]`` (18 numbers, 27 FMAs) instead of a dense 6x6 (reference `_topology_helpers.py:224,324-328`
+already notes TL == BR and TR == 0).  Per-link spatial inertias are emitted as literal-constant matvecs so the
+constants ride in the instruction stream (structural zeros are pruned at generation time).
+"""
+
+_SPATIAL_LIBRARY = r"""
+// ---------------------------------------------------------------------------------------------
+// wave-level hand-off: LDS operations of one wavefront execute in issue order, so a lane group
+// (which never straddles a wave) only needs the compiler fenced, not an s_barrier.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void grid_wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// X is stored compactly per joint: X[0..8] = E (row-major 3x3, top-left == bottom-right block),
+// X[9..17] = B (bottom-left block); the top-right block is identically zero.
+#define GRID_X_STRIDE 20  // floats per joint in LDS (18 used; keeps every joint 16-byte aligned)
+
+template <typename T>
+__device__ __forceinline__ void grid_load_X(T (&X)[18], const T *s_Xj) {
+    #pragma unroll
+    for (int i = 0; i < 18; i++) { X[i] = s_Xj[i]; }
+}
+
+// y = X * v   (motion vector, parent -> child coordinates)
+template <typename T>
+__device__ __forceinline__ void grid_xmul(T (&y)[6], const T (&X)[18], const T (&v)[6]) {
+    #pragma unroll
+    for (int r = 0; r < 3; r++) {
+        y[r]   = X[3*r]*v[0] + X[3*r+1]*v[1] + X[3*r+2]*v[2];
+        y[r+3] = X[9+3*r]*v[0] + X[9+3*r+1]*v[1] + X[9+3*r+2]*v[2] + X[3*r]*v[3] + X[3*r+1]*v[4] + X[3*r+2]*v[5];
+    }
+}
+
+// y += X^T * f   (force vector, child -> parent coordinates)
+template <typename T>
+__device__ __forceinline__ void grid_xtmul_peq(T (&y)[6], const T (&X)[18], const T (&f)[6]) {
+    #pragma unroll
+    for (int r = 0; r < 3; r++) {
+        y[r]   += X[r]*f[0] + X[3+r]*f[1] + X[6+r]*f[2] + X[9+r]*f[3] + X[12+r]*f[4] + X[15+r]*f[5];
+        y[r+3] += X[r]*f[3] + X[3+r]*f[4] + X[6+r]*f[5];
+    }
+}
+
+// y = X^T * f
+template <typename T>
+__device__ __forceinline__ void grid_xtmul(T (&y)[6], const T (&X)[18], const T (&f)[6]) {
+    #pragma unroll
+    for (int r = 0; r < 3; r++) {
+        y[r]   = X[r]*f[0] + X[3+r]*f[1] + X[6+r]*f[2] + X[9+r]*f[3] + X[12+r]*f[4] + X[15+r]*f[5];
+        y[r+3] = X[r]*f[3] + X[3+r]*f[4] + X[6+r]*f[5];
+    }
+}
+
+// out += alpha * crm(vec) * S   for the unit motion subspace S = e_SIND  (the reference's mx0..mx5 family)
+template <typename T, int SIND>
+__device__ __forceinline__ void grid_mxS_peq(T (&out)[6], const T (&vec)[6], const T alpha) {
+    if (SIND == 0) { out[1] += vec[2]*alpha; out[2] -= vec[1]*alpha; out[4] += vec[5]*alpha; out[5] -= vec[4]*alpha; }
+    if (SIND == 1) { out[0] -= vec[2]*alpha; out[2] += vec[0]*alpha; out[3] -= vec[5]*alpha; out[5] += vec[3]*alpha; }
+    if (SIND == 2) { out[0] += vec[1]*alpha; out[1] -= vec[0]*alpha; out[3] += vec[4]*alpha; out[4] -= vec[3]*alpha; }
+    if (SIND == 3) { out[4] += vec[2]*alpha; out[5] -= vec[1]*alpha; }
+    if (SIND == 4) { out[3] -= vec[2]*alpha; out[5] += vec[0]*alpha; }
+    if (SIND == 5) { out[3] += vec[1]*alpha; out[4] -= vec[0]*alpha; }
+}
+
+// out += crf(a) * b   (force cross product; the reference's fx_times_v_peq)
+template <typename T>
+__device__ __forceinline__ void grid_fxv_peq(T (&out)[6], const T (&a)[6], const T (&b)[6]) {
+    out[0] += -a[2]*b[1] + a[1]*b[2] - a[5]*b[4] + a[4]*b[5];
+    out[1] +=  a[2]*b[0] - a[0]*b[2] + a[5]*b[3] - a[3]*b[5];
+    out[2] += -a[1]*b[0] + a[0]*b[1] - a[4]*b[3] + a[3]*b[4];
+    out[3] += -a[2]*b[4] + a[1]*b[5];
+    out[4] +=  a[2]*b[3] - a[0]*b[5];
+    out[5] += -a[1]*b[3] + a[0]*b[4];
+}
+
+template <typename T>
+__device__ __forceinline__ void grid_zero6(T (&v)[6]) {
+    #pragma unroll
+    for (int r = 0; r < 6; r++) { v[r] = static_cast<T>(0); }
+}
+
+template <typename T>
+__device__ __forceinline__ T grid_dot6(const T (&a)[6], const T (&b)[6]) {
+    return a[0]*b[0] + a[1]*b[1] + a[2]*b[2] + a[3]*b[3] + a[4]*b[4] + a[5]*b[5];
+}
+"""
+
+
+def _lit(x):
+    """C++ literal for a model constant (double literal, cast to T at compile time by the caller)."""
+    return repr(float(x))
+
+
+def gen_spatial_algebra_helpers(self):
+    """Emit the register 6-vector library plus one literal-constant inertia matvec per link."""
+    for line in _SPATIAL_LIBRARY.strip("\n").split("\n"):
+        self.gen_add_code_line(line)
+    self.gen_add_code_line("")
+    m = self.model
+    for i in range(m.n):
+        I = m.I[i]
+        self.gen_add_code_line("// y = I[" + str(i) + "] * x  (spatial inertia of link " + str(i) + " as instruction-stream constants)")
+        self.gen_add_code_line("template <typename T>")
+        self.gen_add_code_line("__device__ __forceinline__ void grid_imul_" + str(i) + "(T (&y)[6], const T (&x)[6]) {", True)
+        for r in range(6):
+            terms = [("static_cast<T>(" + _lit(I[r, c]) + ")*x[" + str(c) + "]") for c in range(6) if I[r, c] != 0.0]
+            self.gen_add_code_line("y[" + str(r) + "] = " + (" + ".join(terms) if terms else "static_cast<T>(0)") + ";")
+        self.gen_add_end_function()
+
+
+def gen_mx_func_call_for_cpp(self, S_index, out_name, vec_name, alpha="static_cast<T>(1)"):
+    """Generation-time dispatch on the joint's motion subspace (reference helpers/_spatial_algebra_helpers.py:1-33
+    picks mx<S> at generation time when all S are equal, else a runtime switch; joints are unrolled here so the
+    subspace is always a compile-time constant)."""
+    return "grid_mxS_peq<T," + str(S_index) + ">(" + out_name + ", " + vec_name + ", " + alpha + ");"

@@ -1,0 +1,179 @@
+"""Model constants, LDS layout and the X(q) update for the HIP/CDNA4 backend.
+
+Replaces the hot-path parts of the reference's helpers/_topology_helpers.py (gen_get_XI_size :4, gen_init_XImats :27,
+gen_load_update_XImats_helpers :155-331, gen_init_topology_helpers :544, gen_init_robotModel :715).
+
+Differences by design (documented in DESIGN.md):
+  * the generator classifies constant / q-dependent entries numerically (X(q) = X_J(q) * X(0)), no sympy
+    ``is_constant()`` per entry (the reference spends 50-120 s there for 12-30 DoF robots);
+  * the device constant table d_XImats holds, per joint, the compact tree transform [E_T(9) | B_T(9)] followed by the
+    column-major 6x6 inertias; per solve only the 18 distinct entries of X(q) live in LDS (reference: 72 floats/joint);
+  * the X update is done by lane j for joint j in parallel (reference: serial on thread 0, :221-265) and evaluates
+    sin/cos in T (reference: double literals then cast).
+"""
+import numpy as np
+
+
+def _pad4(x):
+    return (x + 3) // 4 * 4
+
+
+def gen_lds_layout(self):
+    """Per-solve LDS slice (in units of T).  The slice stride is made an odd multiple of 4 dwords so that the
+    lane groups of one wave (which read the *same offset* of *different* slices with broadcast ds_reads) land in
+    different LDS banks."""
+    n = self.model.n
+    off = {}
+    cur = 0
+    for name, size in (("IN", _pad4(4 * n)),          # q | qd | u  (| spare: qdd input for the qdd/Minv overloads)
+                       ("X", 20 * n),                 # compact X(q): 18 of every 20
+                       ("U", 8 * n),                  # U_i (6), 1/D_i, pad
+                       ("T", 48),                     # 6x6 transpose scratch (row stride 8)
+                       ("MINV", _pad4(n * n)),        # dense symmetric M^-1 (col*n+row == row*n+col)
+                       ("QDD", _pad4(n)),
+                       ("OUT", _pad4(2 * n * n))):    # output staging for coalesced stores
+        off[name] = cur
+        cur += size
+    if (cur // 4) % 2 == 0:
+        cur += 4
+    off["TOTAL"] = cur
+    return off
+
+
+def gen_get_XI_size(self, include_base_inertia=False, include_homogenous_transforms=False):
+    """Floats in the device constant table: 18 (compact X_tree) + 36 (inertia) per joint."""
+    return 54 * self.model.n
+
+
+def gen_topology_helpers_size(self):
+    return 2 * self.model.n
+
+
+def gen_init_XImats(self, include_base_inertia=False, include_homogenous_transforms=False):
+    m = self.model
+    n = m.n
+    self.gen_add_func_doc("Initializes the model constant table in GPU memory",
+                          ["Memory order is Xtree[0...N] (compact: E row-major 3x3, then B row-major 3x3), I[0...N] (6x6 column-major)"],
+                          [], "A pointer to the XI memory in the GPU")
+    self.gen_add_code_line("template <typename T>")
+    self.gen_add_code_line("__host__")
+    self.gen_add_code_line("T* init_XImats() {", True)
+    size = self.gen_get_XI_size()
+    self.gen_add_code_line("T *h_XImats = (T *)malloc(" + str(size) + "*sizeof(T));")
+    for i in range(n):
+        XT = m.X_tree[i]
+        vals = [XT[r, c] for r in range(3) for c in range(3)] + [XT[3 + r, c] for r in range(3) for c in range(3)]
+        self.gen_add_code_line("// Xtree[" + str(i) + "]")
+        for k, v in enumerate(vals):
+            self.gen_add_code_line("h_XImats[" + str(18 * i + k) + "] = static_cast<T>(" + repr(float(v)) + ");")
+    for i in range(n):
+        self.gen_add_code_line("// I[" + str(i) + "]")
+        for col in range(6):
+            for row in range(6):
+                self.gen_add_code_line("h_XImats[" + str(18 * n + 36 * i + 6 * col + row) + "] = static_cast<T>(" + repr(float(m.I[i][row, col])) + ");")
+    self.gen_add_code_line("T *d_XImats; gpuErrchk(hipMalloc((void**)&d_XImats," + str(size) + "*sizeof(T)));")
+    self.gen_add_code_line("gpuErrchk(hipMemcpy(d_XImats,h_XImats," + str(size) + "*sizeof(T),hipMemcpyHostToDevice));")
+    self.gen_add_code_line("free(h_XImats);")
+    self.gen_add_code_line("return d_XImats;")
+    self.gen_add_end_function()
+
+
+def gen_init_topology_helpers(self):
+    m = self.model
+    n = m.n
+    self.gen_add_func_doc("Initializes the topology table in GPU memory",
+                          ["Memory order is parent_id[0...N], S_index[0...N]; the generated kernels bake the topology into the",
+                           "instruction stream and do not read this table - it is kept for downstream code that walks the tree"],
+                          [], "A pointer to the topology_helpers memory in the GPU")
+    self.gen_add_code_line("__host__")
+    self.gen_add_code_line("inline int *init_topology_helpers(){", True)
+    vals = [str(p) for p in m.parent] + [str(s) for s in m.S_index]
+    self.gen_add_code_line("int h_topology_helpers[] = {" + ",".join(vals) + "};")
+    self.gen_add_code_line("int *d_topology_helpers; gpuErrchk(hipMalloc((void**)&d_topology_helpers," + str(2 * n) + "*sizeof(int)));")
+    self.gen_add_code_line("gpuErrchk(hipMemcpy(d_topology_helpers,h_topology_helpers," + str(2 * n) + "*sizeof(int),hipMemcpyHostToDevice));")
+    self.gen_add_code_line("return d_topology_helpers;")
+    self.gen_add_end_function()
+
+
+def gen_init_robotModel(self):
+    self.gen_add_func_doc("Initializes the robotModel helpers in GPU memory", [], [], "A pointer to the robotModel struct in GPU memory")
+    self.gen_add_code_line("template <typename T>")
+    self.gen_add_code_line("__host__")
+    self.gen_add_code_line("robotModel<T>* init_robotModel() {", True)
+    self.gen_add_code_lines(["robotModel<T> h_robotModel;",
+                             "h_robotModel.d_XImats = init_XImats<T>();",
+                             "h_robotModel.d_topology_helpers = init_topology_helpers();",
+                             "robotModel<T> *d_robotModel; gpuErrchk(hipMalloc((void**)&d_robotModel,sizeof(robotModel<T>)));",
+                             "gpuErrchk(hipMemcpy(d_robotModel,&h_robotModel,sizeof(robotModel<T>),hipMemcpyHostToDevice));",
+                             "return d_robotModel;"])
+    self.gen_add_end_function()
+
+
+def gen_load_update_XImats_helpers_function_call(self, use_thread_group=False, updated_var_names=None):
+    var = dict(s_X_name="s_X", s_q_name="s_q")
+    if updated_var_names is not None:
+        var.update(updated_var_names)
+    self.gen_add_code_line("load_update_XImats_helpers<T>(" + var["s_X_name"] + ", " + var["s_q_name"] + ", d_robotModel, lane);")
+    self.gen_add_sync(use_thread_group)
+
+
+def gen_load_update_XImats_helpers(self, use_thread_group=False):
+    """Lane j evaluates X_j(q_j) = X_J(q_j) * Xtree_j into this solve's LDS slice (18 floats)."""
+    m = self.model
+    n = m.n
+    self.gen_add_code_lines(["__device__ __forceinline__ void grid_sincos(const float x, float *s, float *c) { sincosf(x, s, c); }",
+                             "__device__ __forceinline__ void grid_sincos(const double x, double *s, double *c) { sincos(x, s, c); }", ""])
+    self.gen_add_func_doc("Updates the joint transforms X(q) of one solve in LDS",
+                          ["lane j of the solve's lane group handles joint j; only the rows of E and B that the joint motion mixes are",
+                           "recomputed (12 of 18 numbers per joint), the remaining row is copied from the constant table"],
+                          ["s_X is this solve's compact transform storage (GRID_X_STRIDE floats per joint)",
+                           "s_q is the vector of joint positions in LDS",
+                           "d_robotModel is the pointer to the initialized model specific helpers on the GPU",
+                           "lane is the caller's lane index inside the solve's lane group"], None)
+    self.gen_add_code_line("template <typename T>")
+    self.gen_add_code_line("__device__ __forceinline__")
+    self.gen_add_code_line("void load_update_XImats_helpers(T *s_X, const T *s_q, const robotModel<T> *d_robotModel, const int lane) {", True)
+    self.gen_add_code_line("if (lane < " + str(n) + ") {", True)
+    self.gen_add_code_lines(["const T *XT = &d_robotModel->d_XImats[18*lane];",
+                             "T *Xo = &s_X[GRID_X_STRIDE*lane];",
+                             "const T q = s_q[lane];"])
+    types = sorted(set(m.S_index))
+    first = True
+    for s in types:
+        ids = [j for j in range(n) if m.S_index[j] == s]
+        cond = "" if len(types) == 1 else (("if " if first else "else if ") + self.gen_lane_mask_test(ids) + " ")
+        first = False
+        a = s % 3
+        r1, r2 = (a + 1) % 3, (a + 2) % 3
+        self.gen_add_code_line(cond + "{ // " + ("revolute" if s < 3 else "prismatic") + " about " + "xyz"[a] + ": joints " + str(ids), True)
+        if s < 3:
+            self.gen_add_code_line("T sn, cs; grid_sincos(q, &sn, &cs);")
+            self.gen_add_code_line("#pragma unroll")
+            self.gen_add_code_line("for (int c = 0; c < 3; c++) {", True)
+            for blk in (0, 9):
+                self.gen_add_code_line("Xo[%d+c] = cs*XT[%d+c] + sn*XT[%d+c];" % (blk + 3 * r1, blk + 3 * r1, blk + 3 * r2))
+                self.gen_add_code_line("Xo[%d+c] = cs*XT[%d+c] - sn*XT[%d+c];" % (blk + 3 * r2, blk + 3 * r2, blk + 3 * r1))
+                self.gen_add_code_line("Xo[%d+c] = XT[%d+c];" % (blk + 3 * a, blk + 3 * a))
+            self.gen_add_end_control_flow()
+        else:
+            self.gen_add_code_line("#pragma unroll")
+            self.gen_add_code_line("for (int c = 0; c < 9; c++) { Xo[c] = XT[c]; }")
+            self.gen_add_code_line("#pragma unroll")
+            self.gen_add_code_line("for (int c = 0; c < 3; c++) {", True)
+            self.gen_add_code_line("Xo[%d+c] = XT[%d+c] + q*XT[%d+c];" % (9 + 3 * r1, 9 + 3 * r1, 3 * r2))
+            self.gen_add_code_line("Xo[%d+c] = XT[%d+c] - q*XT[%d+c];" % (9 + 3 * r2, 9 + 3 * r2, 3 * r1))
+            self.gen_add_code_line("Xo[%d+c] = XT[%d+c];" % (9 + 3 * a, 9 + 3 * a))
+            self.gen_add_end_control_flow()
+        self.gen_add_end_control_flow()
+    self.gen_add_end_control_flow()
+    self.gen_add_end_function()
+
+
+def gen_topology_sparsity_helpers_python(self):
+    """Column bookkeeping the reference needs for its sparsity-compressed layout (helpers/_topology_helpers.py:515-542).
+    With lane j owning columns d/dq_j and d/dq'_j, zeros propagate structurally and no compressed layout is needed;
+    the counts are still reported because SUGGESTED_THREADS-style sizing and DESIGN.md quote them."""
+    m = self.model
+    dva_cols = sum(len(a) + 1 for a in m.ancestors)
+    df_cols = sum(len(m.ancestors[j]) + len(m.subtree[j]) for j in range(m.n))
+    return dva_cols, df_cols

@@ -1,0 +1,169 @@
+"""Build + ctypes binding of the robot-specialised C-ABI library (include/grid_capi.h).
+
+``build_library(robot)`` runs the generator, then hipcc for gfx950, and leaves ``libgrid_<robot>.so`` in-tree
+(gridcodegenerator_amd/_build/<robot>/) so that it travels with the repository snapshot.  ``GridLibrary`` loads it.
+There is no CPU fallback: if the library is missing or does not load, GridLibrary raises.
+"""
+import ctypes
+import os
+import shutil
+import subprocess
+
+import numpy as np
+
+from .GRiDCodeGenerator import GRiDCodeGenerator
+from .robot import RobotModel
+
+PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+REPO_DIR = os.path.dirname(PKG_DIR)
+BUILD_DIR = os.path.join(PKG_DIR, "_build")
+CAPI_SRC = os.path.join(PKG_DIR, "csrc", "grid_capi.hip")
+INCLUDE_DIR = os.path.join(REPO_DIR, "include")
+
+# -fno-slp-vectorize: the SLP vectorizer pairs the unrolled 6-vector arithmetic into v_pk_*_f32, which on gfx950 has the
+# same FLOP rate as scalar v_fma_f32 but needs even-aligned register pairs, extra v_mov shuffles and constants held in
+# VGPR pairs (measured: +60 VGPRs and scratch spills in the RNEA kernel).
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-shared", "-fPIC", "-Wno-unused-value"]
+
+
+def library_path(robot_name, build_dir=None):
+    return os.path.join(build_dir or BUILD_DIR, robot_name, "libgrid_%s.so" % robot_name)
+
+
+def generate_header(robot, out_dir, namespace="grid"):
+    """Runs GRiDCodeGenerator(robot).gen_all_code() with out_dir as the working directory (the generator writes
+    <namespace>.cuh into the cwd, like the reference does)."""
+    os.makedirs(out_dir, exist_ok=True)
+    cwd = os.getcwd()
+    os.chdir(out_dir)
+    try:
+        GRiDCodeGenerator(robot, FILE_NAMESPACE=namespace).gen_all_code()
+    finally:
+        os.chdir(cwd)
+    return os.path.join(out_dir, namespace + ".cuh")
+
+
+def build_library(robot, build_dir=None, force=False, extra_flags=(), verbose=False):
+    """robot: a fixture name, a RobotModel, or any URDFParser-style robot object.  Returns the .so path."""
+    if isinstance(robot, str):
+        robot = RobotModel.from_fixture(robot)
+    name = robot.name
+    out_dir = os.path.join(build_dir or BUILD_DIR, name)
+    so = library_path(name, build_dir)
+    header = generate_header(robot, out_dir)
+    stamp = so + ".stamp"
+    srcs_mtime = max(os.path.getmtime(p) for p in (header, CAPI_SRC, os.path.join(INCLUDE_DIR, "grid_capi.h")))
+    sig = open(header).read() + open(CAPI_SRC).read() + " ".join(HIPCC_FLAGS + list(extra_flags))
+    import hashlib
+    digest = hashlib.sha256(sig.encode()).hexdigest()
+    if not force and os.path.exists(so) and os.path.exists(stamp) and open(stamp).read() == digest:
+        return so
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    cmd = [hipcc] + HIPCC_FLAGS + list(extra_flags) + ["-I" + out_dir, "-I" + INCLUDE_DIR, '-DGRID_ROBOT_NAME="%s"' % name, CAPI_SRC, "-o", so]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    with open(stamp, "w") as f:
+        f.write(digest)
+    return so
+
+
+_c_float_p = ctypes.POINTER(ctypes.c_float)
+
+
+def _ptr(x):
+    """Accepts a raw device/host address (int), a numpy float32 array, or anything with data_ptr() (torch tensors)."""
+    if x is None:
+        return ctypes.c_void_p(None)
+    if isinstance(x, int):
+        return ctypes.c_void_p(x)
+    if hasattr(x, "data_ptr"):
+        return ctypes.c_void_p(x.data_ptr())
+    if isinstance(x, np.ndarray):
+        if x.dtype != np.float32 or not x.flags["C_CONTIGUOUS"]:
+            raise TypeError("expected a C-contiguous float32 array")
+        return ctypes.c_void_p(x.ctypes.data)
+    raise TypeError("cannot interpret %r as a pointer" % type(x))
+
+
+class GridError(RuntimeError):
+    pass
+
+
+class GridLibrary:
+    """Thin ctypes mirror of include/grid_capi.h for one robot."""
+
+    def __init__(self, path, device=0, max_timesteps=16384):
+        if not os.path.exists(path):
+            raise GridError("robot library %s is missing - run gridcodegenerator_amd.runtime.build_library() / __graft_entry__.build(); "
+                            "there is no CPU fallback" % path)
+        self.path = path
+        self.lib = ctypes.CDLL(path)
+        L = self.lib
+        L.grid_robot_name.restype = ctypes.c_char_p
+        L.grid_last_error.restype = ctypes.c_char_p
+        self.n = L.grid_num_joints()
+        self.robot_name = L.grid_robot_name().decode()
+        self.lanes_per_solve = L.grid_lanes_per_solve()
+        self.suggested_threads = L.grid_suggested_threads()
+        self.lds_bytes_per_block = L.grid_lds_bytes_per_block()
+        self.handle = ctypes.c_void_p()
+        self._check(L.grid_init(ctypes.c_int(device), ctypes.c_int(max_timesteps), ctypes.byref(self.handle)))
+        self.max_timesteps = max_timesteps
+
+    def _check(self, rc):
+        if rc != 0:
+            raise GridError("%s (code %d)" % (self.lib.grid_last_error().decode(), rc))
+
+    def close(self):
+        if self.handle:
+            self._check(self.lib.grid_close(self.handle))
+            self.handle = ctypes.c_void_p()
+
+    def set_launch_dims(self, blocks=0, threads=0):
+        self._check(self.lib.grid_set_launch_dims(self.handle, ctypes.c_int(blocks), ctypes.c_int(threads)))
+
+    # ---- host-buffer entry point (H2D, launch, D2H, synchronous)
+    def forward_dynamics_gradient_host(self, q_qd_u, gravity=9.81):
+        x = np.ascontiguousarray(q_qd_u, dtype=np.float32)
+        if x.ndim != 2 or x.shape[1] != 3 * self.n:
+            raise ValueError("q_qd_u must have shape (N, %d)" % (3 * self.n))
+        N = x.shape[0]
+        out = np.empty((N, 2 * self.n * self.n), dtype=np.float32)
+        self._check(self.lib.grid_forward_dynamics_gradient_host(self.handle, _ptr(x), ctypes.c_int(N), ctypes.c_float(gravity), _ptr(out)))
+        return out
+
+    def forward_dynamics_gradient_single_timing(self, q_qd_u_one, reps, gravity=9.81):
+        x = np.ascontiguousarray(q_qd_u_one, dtype=np.float32).reshape(3 * self.n)
+        out = np.empty(2 * self.n * self.n, dtype=np.float32)
+        us = ctypes.c_double()
+        self._check(self.lib.grid_forward_dynamics_gradient_single_timing(self.handle, _ptr(x), ctypes.c_int(reps), ctypes.c_float(gravity), _ptr(out), ctypes.byref(us)))
+        return out, us.value
+
+    # ---- device-pointer entry points (asynchronous on `stream`)
+    def forward_dynamics_gradient_device(self, d_q_qd_u, N, d_df_du, stride=None, gravity=9.81, stream=0):
+        self._check(self.lib.grid_forward_dynamics_gradient_device(self.handle, _ptr(d_q_qd_u), ctypes.c_int(stride or 3 * self.n), ctypes.c_int(N),
+                                                                   ctypes.c_float(gravity), _ptr(d_df_du), ctypes.c_void_p(stream)))
+
+    def forward_dynamics_gradient_qdd_minv_device(self, d_q_qd, d_qdd, d_Minv, N, d_df_du, stride=None, gravity=9.81, stream=0):
+        self._check(self.lib.grid_forward_dynamics_gradient_qdd_minv_device(self.handle, _ptr(d_q_qd), ctypes.c_int(stride or 3 * self.n), _ptr(d_qdd), _ptr(d_Minv),
+                                                                            ctypes.c_int(N), ctypes.c_float(gravity), _ptr(d_df_du), ctypes.c_void_p(stream)))
+
+    def inverse_dynamics_device(self, d_q_qd, d_qdd, N, d_c, stride=None, gravity=9.81, stream=0):
+        self._check(self.lib.grid_inverse_dynamics_device(self.handle, _ptr(d_q_qd), ctypes.c_int(stride or 3 * self.n), _ptr(d_qdd), ctypes.c_int(N),
+                                                          ctypes.c_float(gravity), _ptr(d_c), ctypes.c_void_p(stream)))
+
+    def direct_minv_device(self, d_q, N, d_Minv, stride=None, stream=0):
+        self._check(self.lib.grid_direct_minv_device(self.handle, _ptr(d_q), ctypes.c_int(stride or 3 * self.n), ctypes.c_int(N), _ptr(d_Minv), ctypes.c_void_p(stream)))
+
+    def forward_dynamics_device(self, d_q_qd_u, N, d_qdd, stride=None, gravity=9.81, stream=0):
+        self._check(self.lib.grid_forward_dynamics_device(self.handle, _ptr(d_q_qd_u), ctypes.c_int(stride or 3 * self.n), ctypes.c_int(N),
+                                                          ctypes.c_float(gravity), _ptr(d_qdd), ctypes.c_void_p(stream)))
+
+    def inverse_dynamics_gradient_device(self, d_q_qd, d_qdd, N, d_dc_du, stride=None, gravity=9.81, stream=0):
+        self._check(self.lib.grid_inverse_dynamics_gradient_device(self.handle, _ptr(d_q_qd), ctypes.c_int(stride or 3 * self.n), _ptr(d_qdd), ctypes.c_int(N),
+                                                                   ctypes.c_float(gravity), _ptr(d_dc_du), ctypes.c_void_p(stream)))
+
+
+def load(robot_name, device=0, max_timesteps=16384, build_dir=None):
+    return GridLibrary(library_path(robot_name, build_dir), device=device, max_timesteps=max_timesteps)

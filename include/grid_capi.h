@@ -1,0 +1,77 @@
+/*
+ * grid_capi.h - C ABI of a robot-specialised GRiD library for AMD MI355X (gfx950).
+ *
+ * One shared library is built per robot (libgrid_<robot>.so) from the header emitted by
+ * gridcodegenerator_amd.GRiDCodeGenerator(robot).gen_all_code() plus gridcodegenerator_amd/csrc/grid_capi.hip.
+ * The entry points below are what a foreign-function binding (ctypes, cgo, JNI ...) of the reference's emitted
+ * C++ host API would bind; each cites the reference interface it replaces.  Plain pointers and sizes only.
+ *
+ * Conventions
+ *   - every function returns 0 on success or a non-zero hipError_t value; grid_last_error() gives the text
+ *     (the reference's host API instead prints "GPUassert: ..." and exit()s, reference GRiDCodeGenerator.py:279-286);
+ *   - T is float ("Suggested Type T is float", reference GRiDCodeGenerator.py:378);
+ *   - layouts (reference algorithms/_forward_dynamics_gradient.py:50,61,168 and SURVEY.md section 8(a) a1):
+ *       q_qd_u [k*stride + {0..n | n..2n | 2n..3n}]            inputs, array-of-structs over the batch index k
+ *       df_du  [k*2n^2 + col*n + row], col in [0,2n)           = [d qdd/d q | d qdd/d qd], column-major n x 2n
+ *       dc_du  same shape as df_du;  Minv [k*n^2 + col*n + row] (upper triangle, column-major);  c, qdd [k*n + i]
+ *   - gravity is passed POSITIVE (9.81), as in the reference's emitted code (reference _inverse_dynamics.py:123);
+ *   - *_device entry points take DEVICE pointers and enqueue on `stream` (a hipStream_t passed as void*, NULL = default
+ *     stream) without synchronising; *_host entry points take HOST pointers, copy in, run, copy out and synchronise.
+ *   - one handle per GPU; a handle is not thread-safe.
+ */
+#ifndef GRID_CAPI_H
+#define GRID_CAPI_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct grid_handle grid_handle;
+
+/* robot the library was generated for (constants NUM_JOINTS etc., reference GRiDCodeGenerator.py:94-111) */
+int grid_num_joints(void);
+const char *grid_robot_name(void);
+int grid_lanes_per_solve(void);
+int grid_suggested_threads(void);
+int grid_lds_bytes_per_block(void);
+const char *grid_last_error(void);
+
+/* replaces init_robotModel<T>() + init_grid<T>() + init_gridData<T>(max_timesteps)
+ * (reference helpers/_topology_helpers.py:715-730, GRiDCodeGenerator.py:160-271) */
+int grid_init(int device, int max_timesteps, grid_handle **out);
+/* replaces close_grid<T>() (reference GRiDCodeGenerator.py:252-271) */
+int grid_close(grid_handle *h);
+
+/* replaces forward_dynamics_gradient<T,false>(hd_data, d_robotModel, gravity, num_timesteps, block, thread, streams)
+ * (reference algorithms/_forward_dynamics_gradient.py:186-249): host buffers in, host buffers out, synchronous */
+int grid_forward_dynamics_gradient_host(grid_handle *h, const float *h_q_qd_u, int num_timesteps, float gravity, float *h_df_du);
+/* replaces forward_dynamics_gradient_compute_only<T,false> / a direct forward_dynamics_gradient_kernel<T> launch
+ * (reference algorithms/_forward_dynamics_gradient.py:113-184,203-234): device buffers, asynchronous on `stream` */
+int grid_forward_dynamics_gradient_device(grid_handle *h, const float *d_q_qd_u, int stride_q_qd_u, int num_timesteps, float gravity,
+                                          float *d_df_du, void *stream);
+/* the (q,qd,qdd,Minv)-input overload, USE_QDD_MINV_FLAG=true (reference :126-130,160,233) */
+int grid_forward_dynamics_gradient_qdd_minv_device(grid_handle *h, const float *d_q_qd, int stride_q_qd, const float *d_qdd, const float *d_Minv,
+                                                   int num_timesteps, float gravity, float *d_df_du, void *stream);
+/* launch geometry override for the *_device entry points (0 = library default).  The reference API takes
+ * block_dimms/thread_dimms from the caller on every call (reference :198-199). */
+int grid_set_launch_dims(grid_handle *h, int blocks, int threads);
+
+/* SURVEY.md section 8(f) "next" rows: the stand-alone algorithms the hot path is composed of */
+/* replaces inverse_dynamics_kernel<T> (reference algorithms/_inverse_dynamics.py:371-438); d_qdd may be NULL (qdd = 0) */
+int grid_inverse_dynamics_device(grid_handle *h, const float *d_q_qd, int stride_q_qd, const float *d_qdd, int num_timesteps, float gravity,
+                                 float *d_c, void *stream);
+/* replaces direct_minv_kernel<T> (reference algorithms/_direct_minv.py:478-525) */
+int grid_direct_minv_device(grid_handle *h, const float *d_q, int stride_q, int num_timesteps, float *d_Minv, void *stream);
+/* replaces forward_dynamics_kernel<T> (reference algorithms/_forward_dynamics.py:149-199) */
+int grid_forward_dynamics_device(grid_handle *h, const float *d_q_qd_u, int stride_q_qd_u, int num_timesteps, float gravity, float *d_qdd, void *stream);
+/* replaces inverse_dynamics_gradient_kernel<T> (reference algorithms/_inverse_dynamics_gradient.py:817-888); d_qdd may be NULL */
+int grid_inverse_dynamics_gradient_device(grid_handle *h, const float *d_q_qd, int stride_q_qd, const float *d_qdd, int num_timesteps, float gravity,
+                                          float *d_dc_du, void *stream);
+
+/* in-kernel timing probe: replaces forward_dynamics_gradient_single_timing<T> (reference :236-248); returns microseconds per solve */
+int grid_forward_dynamics_gradient_single_timing(grid_handle *h, const float *h_q_qd_u, int reps, float gravity, float *h_df_du, double *us_per_call);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GRID_CAPI_H */

@@ -1,0 +1,87 @@
+// tests/emu/hip/hip_runtime.h - HOST EMULATION of the small HIP surface the generated header uses.
+// TEST INFRASTRUCTURE ONLY (lives under tests/): lets `g++ -std=c++20 -Itests/emu` compile the *unchanged* generated
+// grid.cuh and run its kernels on the CPU so that the generated algorithm/indexing/topology logic can be checked against
+// the oracle without a GPU (`pytest -m "not gpu"`).  One OS thread per GPU thread of a block, blocks run one after
+// another, the wave-level sync is a barrier over the block's threads.  It is never used by the product.
+#pragma once
+#ifndef _GNU_SOURCE
+#define _GNU_SOURCE
+#endif
+#include <barrier>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <memory>
+#include <thread>
+#include <vector>
+
+#define __host__
+#define __device__
+#define __global__
+#define __forceinline__ inline
+#define __shared__
+#define __launch_bounds__(...)
+
+struct dim3 {
+    unsigned x, y, z;
+    dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
+};
+inline thread_local dim3 threadIdx, blockIdx, blockDim, gridDim;
+
+typedef int hipError_t;
+typedef void *hipStream_t;
+enum { hipSuccess = 0, hipErrorInvalidValue = 1, hipErrorInvalidConfiguration = 9 };
+enum hipMemcpyKind { hipMemcpyHostToDevice, hipMemcpyDeviceToHost, hipMemcpyDeviceToDevice };
+enum { hipStreamNonBlocking = 1, hipHostMallocDefault = 0 };
+
+inline const char *hipGetErrorString(hipError_t) { return "emulated hip error"; }
+inline hipError_t hipDeviceReset() { return hipSuccess; }
+inline hipError_t hipSetDevice(int) { return hipSuccess; }
+inline hipError_t hipGetLastError() { return hipSuccess; }
+inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
+inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+inline hipError_t hipMalloc(void **p, size_t n) { *p = calloc(1, n ? n : 1); return hipSuccess; }
+inline hipError_t hipHostMalloc(void **p, size_t n, unsigned) { *p = calloc(1, n ? n : 1); return hipSuccess; }
+inline hipError_t hipFree(void *p) { free(p); return hipSuccess; }
+inline hipError_t hipHostFree(void *p) { free(p); return hipSuccess; }
+inline hipError_t hipMemcpy(void *d, const void *s, size_t n, hipMemcpyKind) { memcpy(d, s, n); return hipSuccess; }
+inline hipError_t hipMemcpyAsync(void *d, const void *s, size_t n, hipMemcpyKind, hipStream_t) { memcpy(d, s, n); return hipSuccess; }
+inline hipError_t hipDeviceGetStreamPriorityRange(int *lo, int *hi) { *lo = 0; *hi = 0; return hipSuccess; }
+inline hipError_t hipStreamCreateWithPriority(hipStream_t *s, unsigned, int) { *s = nullptr; return hipSuccess; }
+inline hipError_t hipStreamDestroy(hipStream_t) { return hipSuccess; }
+
+// dynamic LDS of the (single) running block
+alignas(16) unsigned char grid_smem_raw[160 * 1024];  // (one definition: the emulation harness is a single translation unit)
+
+namespace hipemu {
+inline std::barrier<> *g_barrier = nullptr;
+inline void wave_barrier() { g_barrier->arrive_and_wait(); }
+
+template <typename F>
+void launch(dim3 grid, dim3 block, size_t smem_bytes, F &&body) {
+    if (smem_bytes > sizeof(grid_smem_raw)) { fprintf(stderr, "hipemu: dynamic LDS request too large\n"); abort(); }
+    const unsigned nthreads = block.x * block.y * block.z;
+    for (unsigned by = 0; by < grid.y; by++)
+        for (unsigned bx = 0; bx < grid.x; bx++) {
+            std::barrier<> bar(nthreads);
+            g_barrier = &bar;
+            std::vector<std::thread> ts;
+            for (unsigned t = 0; t < nthreads; t++)
+                ts.emplace_back([&, t]() {
+                    threadIdx = dim3(t % block.x, (t / block.x) % block.y, t / (block.x * block.y));
+                    blockIdx = dim3(bx, by, 0);
+                    blockDim = block;
+                    gridDim = grid;
+                    body();
+                    bar.arrive_and_drop();  // a retiring thread no longer takes part in wave-level syncs
+                });
+            for (auto &t : ts) t.join();
+        }
+}
+}  // namespace hipemu
+
+#define __builtin_amdgcn_fence(order, scope) ((void)0)
+#define __builtin_amdgcn_wave_barrier() hipemu::wave_barrier()
+#define hipLaunchKernelGGL(kernel, grid, block, smem, stream, ...) hipemu::launch((grid), (block), (smem), [&]() { kernel(__VA_ARGS__); })

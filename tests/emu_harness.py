@@ -1,0 +1,27 @@
+"""Builds the CPU *emulation* of a robot library: the unchanged generated header + the unchanged C-ABI shim compiled by
+g++ against tests/emu/hip/hip_runtime.h (threads-per-lane emulation).  Test infrastructure only."""
+import os
+import subprocess
+import tempfile
+
+from gridcodegenerator_amd import RobotModel
+from gridcodegenerator_amd.runtime import CAPI_SRC, INCLUDE_DIR, GridLibrary, generate_header
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+EMU_INC = os.path.join(HERE, "emu")
+_CACHE = {}
+
+
+def emu_library(robot, max_timesteps=64):
+    if isinstance(robot, str):
+        robot = RobotModel.from_fixture(robot)
+    key = robot.name
+    if key not in _CACHE:
+        out_dir = os.path.join(tempfile.gettempdir(), "grid_emu_build", key)
+        generate_header(robot, out_dir)
+        so = os.path.join(out_dir, "libgrid_emu_%s.so" % key)
+        cmd = ["g++", "-std=c++20", "-O1", "-g0", "-x", "c++", "-shared", "-fPIC", "-pthread", "-I" + EMU_INC, "-I" + out_dir, "-I" + INCLUDE_DIR,
+               '-DGRID_ROBOT_NAME="%s"' % key, "-Wno-unused-value", CAPI_SRC, "-o", so]
+        subprocess.check_call(cmd)
+        _CACHE[key] = so
+    return GridLibrary(_CACHE[key], device=0, max_timesteps=max_timesteps)
