@@ -1,0 +1,183 @@
+#!/usr/bin/env python3
+"""Headline benchmark: forward_dynamics_gradient solves/sec, iiwa-14, batch 16384 per GPU (BASELINE.json metric).
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+One "step" = one pass of the hot path (one forward_dynamics_gradient_kernel launch through the C ABI) over one batch of
+16384 synthetic solves whose inputs and outputs are resident in HBM.  Every rank owns its own batch (the batch axis shards
+with no collective: "scaling": "weak"); value = solves processed by all ranks / max-over-ranks wall time of the K steps.
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+ROBOT = "iiwa14"
+BATCH = 16384
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec); ~6.3 TB/s measured copy ceiling
+FP32_PEAK_TFLOPS = 157.3       # MI355X_MICROARCH.md: peak FP32 vector
+FLOPS_PER_SOLVE = 53e3         # static estimate of the reference's emitted code, n = 7
+
+
+def make_inputs(n, N, seed=0):
+    """default_rng(0); q~U(-pi,pi), qd~U(-2,2), u~U(-10,10); float32 AoS [k][3n]."""
+    rng = np.random.default_rng(seed)
+    return np.hstack([rng.uniform(-np.pi, np.pi, (N, n)), rng.uniform(-2, 2, (N, n)), rng.uniform(-10, 10, (N, n))]).astype(np.float32)
+
+
+def cpu_baseline(robot, x, budget_s=12.0):
+    """Times the CPU oracle (fp32 build of oracle/rbd_oracle.c, the restatement of the reference's NumPy oracle) on this
+    host's cores: the checker used as a reported baseline, never as part of the measured GPU path."""
+    from oracle import rbd_oracle
+
+    so = None
+    try:  # rebuild for this host's ISA outside the tree (the in-tree .so is the portable build)
+        so = rbd_oracle.build(march="native", out=os.path.join("/tmp", "librbd_oracle_native_%d.so" % os.getpid()), force=True)
+    except Exception:
+        so = None
+    orc = rbd_oracle.Oracle(robot, dtype=np.float32, lib_path=so)
+    sample = x[:2048]
+    orc.fd_grad_batch(sample, nthreads=0)  # warm
+    t0 = time.perf_counter()
+    _, cores = orc.fd_grad_batch(sample, nthreads=0)
+    dt = time.perf_counter() - t0
+    reps = max(1, min(200, int(budget_s / max(dt, 1e-6))))
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        orc.fd_grad_batch(sample, nthreads=0)
+    dt = time.perf_counter() - t0
+    return {"value": reps * sample.shape[0] / dt, "unit": "solves/s", "cores": int(cores), "kind": "port",
+            "sample": "%d x %d iiwa14 solves of the bench batch, fp32 C oracle (oracle/rbd_oracle.c, -O3 -march=native, OpenMP static), %.1f s" % (reps, sample.shape[0], dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--batch", type=int, default=BATCH, help="solves per GPU per step")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--threads", type=int, default=0, help="threads per block override (0 = library default)")
+    ap.add_argument("--blocks", type=int, default=0, help="blocks override (0 = one lane-group batch per block)")
+    args = ap.parse_args()
+
+    import torch
+
+    from gridcodegenerator_amd import RobotModel
+    from gridcodegenerator_amd.runtime import load
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    distributed = world > 1
+    if distributed:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+
+    robot = RobotModel.from_fixture(ROBOT)
+    n = robot.n
+    N = args.batch
+    lib = load(ROBOT, device=local_rank, max_timesteps=N)  # raises if the HIP library is missing (no CPU fallback)
+    if args.threads or args.blocks:
+        lib.set_launch_dims(args.blocks, args.threads)
+    x = make_inputs(n, N, seed=rank)  # every rank owns a different shard of the job
+    d_in = torch.from_numpy(x).to(dev)
+    d_out = torch.empty((N, 2 * n * n), dtype=torch.float32, device=dev)
+    stream = torch.cuda.current_stream(dev)
+
+    def step():
+        lib.forward_dynamics_gradient_device(d_in, N, d_out, stream=stream.cuda_stream)
+
+    def barrier():
+        torch.cuda.synchronize(dev)
+        if distributed:
+            dist.barrier()
+            torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    # ---- timed region: exactly K steps; HIP events on the launch stream bracket it for the per-launch kernel time
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record(stream)
+    for _ in range(args.steps):
+        step()
+    ev1.record(stream)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    gpu_ms = ev0.elapsed_time(ev1)
+    if distributed:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # parity spot check outside the timed region (the product path never touches the oracle)
+    if rank == 0:
+        from oracle.rbd_oracle import Oracle
+
+        got = d_out[:32].cpu().numpy()
+        ref, _ = Oracle(robot).fd_grad_batch(x[:32].astype(np.float64))
+        err = float(max(np.abs(got[k] - ref[k]).max() / np.abs(ref[k]).max() for k in range(32)))
+        assert err <= 1e-4, "parity check failed: %g" % err
+
+        solves = world * N * args.steps
+        bytes_per_solve = 4 * (3 * n + 2 * n * n)  # 476 B for n = 7
+        launch_ms = gpu_ms / args.steps             # average launch duration on the launch stream (HIP events), incl. launch boundaries
+        achieved = bytes_per_solve * N / (launch_ms * 1e-3) / 1e9
+        traffic = None
+        pmc_file = os.path.join(REPO, "profiles", "pmc_traffic.json")
+        if os.path.exists(pmc_file):
+            try:
+                traffic = json.load(open(pmc_file)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        line = {
+            "metric": "forward_dynamics_gradient solves/sec, iiwa-14 batch=16384",
+            "value": solves / elapsed,
+            "unit": "solves/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "iiwa14 (7-DoF chain) forward_dynamics_gradient, batch=%d per GPU, device-resident q_qd_u -> df_du" % N,
+                       "robot": ROBOT, "batch_per_gpu": N, "global_batch": world * N, "sharding": "batch axis, no collective"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "kernel": "forward_dynamics_gradient_kernel<float>", "launch_us": 1e3 * launch_ms,
+                         "algorithmic_bytes_per_launch": bytes_per_solve * N,
+                         "note": "the path is fp32-VALU bound (AI ~110 flop/B): see valu_frac"},
+            "valu_frac": (N / (launch_ms * 1e-3)) * FLOPS_PER_SOLVE / (FP32_PEAK_TFLOPS * 1e12),
+            "parity_max_rel_err_vs_fp64_oracle": err,
+        }
+        if not args.no_cpu_baseline and world == 1:
+            line["cpu_baseline"] = cpu_baseline(robot, x)
+        elif not args.no_cpu_baseline:
+            line["cpu_baseline"] = None
+        print(json.dumps(line))
+    if distributed:
+        dist.barrier()
+        dist.destroy_process_group()
+    lib.close()
+
+
+if __name__ == "__main__":
+    main()
