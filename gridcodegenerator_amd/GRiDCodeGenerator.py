@@ -108,7 +108,7 @@ class GRiDCodeGenerator:
                                  "const int GRID_MAX_SOLVES_PER_BLOCK = SUGGESTED_THREADS/GRID_LANES_PER_SOLVE; // what the *_DYNAMIC_SHARED_MEM_COUNT constants cover",
                                  "// per-solve LDS slice (elements of T) and the offsets of its parts",
                                  "const int GRID_LDS_PER_SOLVE = " + str(lds["TOTAL"]) + ";"])
-        for k in ("IN", "X", "U", "T", "MINV", "QDD", "OUT"):
+        for k in ("IN", "X", "U", "T", "MINV", "QDD", "F", "OUT"):
             self.gen_add_code_line("const int GRID_OFF_" + k + " = " + str(lds[k]) + ";")
         for k in ("ID", "MINV", "FD", "ID_DU", "FD_DU"):
             self.gen_add_code_line("const int " + k + "_DYNAMIC_SHARED_MEM_COUNT = " + str(count) + ";")

@@ -66,7 +66,7 @@ def gen_forward_dynamics_gradient_device(self, use_thread_group=False, use_qdd_M
     self.gen_add_code_line("template <typename T>")
     self.gen_add_code_line("__device__ __forceinline__")
     self.gen_add_code_line(func_def, True)
-    self.gen_add_code_line("T *s_X = &s_work[GRID_OFF_X]; T *s_U = &s_work[GRID_OFF_U]; T *s_T = &s_work[GRID_OFF_T];")
+    self.gen_add_code_line("T *s_X = &s_work[GRID_OFF_X]; T *s_U = &s_work[GRID_OFF_U]; T *s_T = &s_work[GRID_OFF_T]; T *s_F = &s_work[GRID_OFF_F];")
     if not use_qdd_Minv_input:
         self.gen_add_code_line("T *s_Minv = &s_work[GRID_OFF_MINV]; T *s_qdd = &s_work[GRID_OFF_QDD];")
     self.gen_add_code_line("(void)s_U; (void)s_T;")
@@ -105,7 +105,7 @@ def gen_forward_dynamics_gradient_kernel(self, use_thread_group=False, use_qdd_M
         self.gen_add_code_line("T *s_q_qd = &s_mem[GRID_OFF_IN]; T *s_q = s_q_qd; T *s_qd = &s_q_qd[%d]; T *s_qdd = &s_mem[GRID_OFF_QDD];" % n)
     else:
         self.gen_add_code_line("T *s_q_qd_u = &s_mem[GRID_OFF_IN]; T *s_q = s_q_qd_u; T *s_qd = &s_q_qd_u[%d]; T *s_u = &s_q_qd_u[%d]; T *s_qdd = &s_mem[GRID_OFF_QDD];" % (n, 2 * n))
-    self.gen_add_code_line("T *s_X = &s_mem[GRID_OFF_X]; T *s_U = &s_mem[GRID_OFF_U]; T *s_T = &s_mem[GRID_OFF_T]; T *s_Minv = &s_mem[GRID_OFF_MINV]; T *s_df_du = &s_mem[GRID_OFF_OUT];")
+    self.gen_add_code_line("T *s_X = &s_mem[GRID_OFF_X]; T *s_U = &s_mem[GRID_OFF_U]; T *s_T = &s_mem[GRID_OFF_T]; T *s_Minv = &s_mem[GRID_OFF_MINV]; T *s_F = &s_mem[GRID_OFF_F]; T *s_df_du = &s_mem[GRID_OFF_OUT];")
     self.gen_add_code_line("(void)s_U; (void)s_T;")
     if single_call_timing:
         self.gen_add_code_line("const int k = 0; const int kc = 0; const bool valid = (blockIdx.x + blockIdx.y == 0) && (grp == 0);")

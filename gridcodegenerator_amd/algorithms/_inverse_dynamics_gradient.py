@@ -29,7 +29,7 @@ def gen_inverse_dynamics_gradient_kernel_max_temp_mem_size(self):
 
 
 def gen_inverse_dynamics_gradient_inner_function_call(self, use_thread_group=False, updated_var_names=None):
-    self.gen_add_code_line("inverse_dynamics_gradient_inner<T>(dc_dq, dc_dqd, s_qd, s_qdd, s_X, gravity, lane);")
+    self.gen_add_code_line("inverse_dynamics_gradient_inner<T>(dc_dq, dc_dqd, s_qd, s_qdd, s_X, s_F, gravity, lane);")
 
 
 def gen_inverse_dynamics_gradient_inner(self, use_thread_group=False):
@@ -41,17 +41,17 @@ def gen_inverse_dynamics_gradient_inner(self, use_thread_group=False):
                            "follows /root/reference/_test.py:229-494 incl. the damping term on diag(dc/dqd)"],
                           ["dc_dq, dc_dqd are the register outputs", "s_qd is the vector of joint velocities in LDS",
                            "s_qdd is the vector of joint accelerations in LDS", "s_X is this solve's compact X(q) storage",
-                           "gravity is the gravity constant", "lane is the caller's lane index inside the solve's lane group"], None)
+                           "s_F is LDS scratch for the wave-uniform link forces (8 floats per joint)", "gravity is the gravity constant", "lane is the caller's lane index inside the solve's lane group"], None)
     self.gen_add_code_line("template <typename T>")
     self.gen_add_code_line("__device__ __forceinline__")
-    self.gen_add_code_line("void inverse_dynamics_gradient_inner(T (&dc_dq)[%d], T (&dc_dqd)[%d], const T *s_qd, const T *s_qdd, const T *s_X, const T gravity, const int lane) {" % (n, n), True)
+    self.gen_add_code_line("void inverse_dynamics_gradient_inner(T (&dc_dq)[%d], T (&dc_dqd)[%d], const T *s_qd, const T *s_qdd, const T *s_X, T *s_F, const T gravity, const int lane) {" % (n, n), True)
 
     def pre(i):
         s, p = m.S_index[i], m.parent[i]
         I = str(i)
         P = str(p)
         self.gen_add_code_line("const T self_" + I + " = (lane == " + I + ") ? static_cast<T>(1) : static_cast<T>(0);")
-        self.gen_add_code_line("T v_%s[6], a_%s[6], f_%s[6], dvq_%s[6], dvd_%s[6], daq_%s[6], dad_%s[6], dfq_%s[6], dfd_%s[6];" % ((I,) * 9))
+        self.gen_add_code_line("T v_%s[6], a_%s[6], dvq_%s[6], dvd_%s[6], daq_%s[6], dad_%s[6], dfq_%s[6], dfd_%s[6];" % ((I,) * 8))
         self.gen_add_code_line("{", True)
         self.gen_add_code_line("T X[18]; grid_load_X(X, &s_X[GRID_X_STRIDE*" + I + "]);")
         self.gen_add_code_line("const T qd = s_qd[" + I + "]; const T qdd = s_qdd[" + I + "];")
@@ -68,7 +68,12 @@ def gen_inverse_dynamics_gradient_inner(self, use_thread_group=False):
         self.gen_add_code_line("#pragma unroll")
         self.gen_add_code_line("for (int r = 0; r < 6; r++) { a_%s[r] = Xa[r] + Mxv[r]*qd; }" % I)
         self.gen_add_code_line("a_%s[%d] += qdd;" % (I, s))
-        self.gen_add_code_line("grid_imul_%s(Iv, v_%s); grid_imul_%s(f_%s, a_%s); grid_fxv_peq(f_%s, v_%s, Iv);" % (I, I, I, I, I, I, I))
+        self.gen_add_code_line("// the link force is wave-uniform and only needed again on the way back up: park it in LDS instead of 6 VGPRs per level")
+        self.gen_add_code_line("{ T f[6]; grid_imul_%s(Iv, v_%s); grid_imul_%s(f, a_%s); grid_fxv_peq(f, v_%s, Iv);" % (I, I, I, I, I))
+        self.gen_add_code_line("  if (lane == 0) {")
+        self.gen_add_code_line("      #pragma unroll")
+        self.gen_add_code_line("      for (int r = 0; r < 6; r++) { s_F[%d + r] = f[r]; }" % (8 * i))
+        self.gen_add_code_line("  } }")
         self.gen_add_code_line("// this lane's columns: dv, da (forward recursions with the self terms of column == joint)")
         if p == -1:
             self.gen_add_code_line("#pragma unroll")
@@ -94,11 +99,19 @@ def gen_inverse_dynamics_gradient_inner(self, use_thread_group=False):
         self.gen_add_code_line("dc_dq[%s] = dfq_%s[%d];" % (I, I, s))
         self.gen_add_code_line("dc_dqd[%s] = dfd_%s[%d]%s;" % (I, I, s, (" + self_" + I + "*static_cast<T>(" + repr(float(damp)) + ")") if damp != 0.0 else ""))
         if p != -1:
+            self.gen_add_sync(use_thread_group)
             self.gen_add_code_line("{", True)
             self.gen_add_code_line("T X[18]; grid_load_X(X, &s_X[GRID_X_STRIDE*" + I + "]);")
+            self.gen_add_code_line("T f[6], fp[6];")
+            self.gen_add_code_line("#pragma unroll")
+            self.gen_add_code_line("for (int r = 0; r < 6; r++) { f[r] = s_F[%d + r]; fp[r] = s_F[%d + r]; }" % (8 * i, 8 * p))
             self.gen_add_code_line("// column == joint picks up -X^T mxS(f) where f is the accumulated subtree force")
-            self.gen_add_code_line("grid_mxS_peq<T,%d>(dfq_%s, f_%s, -self_%s);" % (s, I, I, I))
-            self.gen_add_code_line("grid_xtmul_peq(f_%s, X, f_%s); grid_xtmul_peq(dfq_%s, X, dfq_%s); grid_xtmul_peq(dfd_%s, X, dfd_%s);" % (P, I, P, I, P, I))
+            self.gen_add_code_line("grid_mxS_peq<T,%d>(dfq_%s, f, -self_%s);" % (s, I, I))
+            self.gen_add_code_line("grid_xtmul_peq(fp, X, f); grid_xtmul_peq(dfq_%s, X, dfq_%s); grid_xtmul_peq(dfd_%s, X, dfd_%s);" % (P, I, P, I))
+            self.gen_add_code_line("if (lane == 0) {", True)
+            self.gen_add_code_line("#pragma unroll")
+            self.gen_add_code_line("for (int r = 0; r < 6; r++) { s_F[%d + r] = fp[r]; }" % (8 * p))
+            self.gen_add_end_control_flow()
             self.gen_add_end_control_flow()
 
     self.gen_tree_traversal(pre, post)
@@ -125,7 +138,7 @@ def gen_inverse_dynamics_gradient_kernel(self, use_thread_group=False, use_qdd_i
     self.gen_add_code_line(func_def, True)
     self.gen_kernel_prologue("GRID_LDS_PER_SOLVE")
     self.gen_add_code_lines(["T *s_q_qd = &s_mem[GRID_OFF_IN]; T *s_q = s_q_qd; T *s_qd = &s_q_qd[%d]; T *s_qdd = &s_q_qd[%d];" % (n, 2 * n),
-                             "T *s_X = &s_mem[GRID_OFF_X]; T *s_dc_du = &s_mem[GRID_OFF_OUT];"])
+                             "T *s_X = &s_mem[GRID_OFF_X]; T *s_F = &s_mem[GRID_OFF_F]; T *s_dc_du = &s_mem[GRID_OFF_OUT];"])
     if single_call_timing:
         self.gen_add_code_line("const int k = 0; const int kc = 0; const bool valid = (blockIdx.x + blockIdx.y == 0) && (grp == 0);")
         self.gen_add_code_line("if (!valid) {return;}")

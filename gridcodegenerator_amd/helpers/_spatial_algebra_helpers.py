@@ -99,20 +99,61 @@ def _lit(x):
     return repr(float(x))
 
 
+def _rigid_body_params(I, tol=1e-12):
+    """If I is a rigid-body spatial inertia [[Ibar, h~],[h~^T, m 1]] return (Ibar(3x3), h(3), m), else None."""
+    import numpy as np
+    m = I[3, 3]
+    if not (np.allclose(I[3:, 3:], m * np.eye(3), atol=tol) and np.allclose(I, I.T, atol=tol)):
+        return None
+    H = I[:3, 3:]
+    h = np.array([H[2, 1], H[0, 2], H[1, 0]])
+    Hs = np.array([[0, -h[2], h[1]], [h[2], 0, -h[0]], [-h[1], h[0], 0]])
+    if not np.allclose(H, Hs, atol=tol):
+        return None
+    return I[:3, :3], h, m
+
+
 def gen_spatial_algebra_helpers(self):
-    """Emit the register 6-vector library plus one literal-constant inertia matvec per link."""
+    """Emit the register 6-vector library plus one literal-constant inertia matvec per link.
+
+    Link inertias are rigid-body inertias (10 parameters: Ibar symmetric 3x3, h = m*c, m), so
+    I*[w;v] = [Ibar w + h x v ; m v - h x w] costs 24 FMAs with 10 constants instead of a dense 36/36;
+    a general symmetric 6x6 (e.g. a caller-supplied composite inertia) falls back to the dense form."""
     for line in _SPATIAL_LIBRARY.strip("\n").split("\n"):
         self.gen_add_code_line(line)
     self.gen_add_code_line("")
     m = self.model
+    C = lambda x: "static_cast<T>(" + _lit(x) + ")"
     for i in range(m.n):
         I = m.I[i]
+        rb = _rigid_body_params(I)
         self.gen_add_code_line("// y = I[" + str(i) + "] * x  (spatial inertia of link " + str(i) + " as instruction-stream constants)")
         self.gen_add_code_line("template <typename T>")
         self.gen_add_code_line("__device__ __forceinline__ void grid_imul_" + str(i) + "(T (&y)[6], const T (&x)[6]) {", True)
-        for r in range(6):
-            terms = [("static_cast<T>(" + _lit(I[r, c]) + ")*x[" + str(c) + "]") for c in range(6) if I[r, c] != 0.0]
-            self.gen_add_code_line("y[" + str(r) + "] = " + (" + ".join(terms) if terms else "static_cast<T>(0)") + ";")
+        if rb is None:
+            for r in range(6):
+                terms = [(C(I[r, c]) + "*x[" + str(c) + "]") for c in range(6) if I[r, c] != 0.0]
+                self.gen_add_code_line("y[" + str(r) + "] = " + (" + ".join(terms) if terms else "static_cast<T>(0)") + ";")
+        else:
+            Ib, h, mass = rb
+            self.gen_add_code_line("// rigid body: y = [Ibar w + h x v ; m v - h x w]")
+            cross = [(1, 2), (2, 0), (0, 1)]  # (h x v)[r] = h[a] v[b] - h[b] v[a]
+            for r in range(3):
+                a, b = cross[r]
+                terms = [(C(Ib[r, c]) + "*x[" + str(c) + "]") for c in range(3) if Ib[r, c] != 0.0]
+                if h[a] != 0.0:
+                    terms.append(C(h[a]) + "*x[" + str(3 + b) + "]")
+                if h[b] != 0.0:
+                    terms.append(C(-h[b]) + "*x[" + str(3 + a) + "]")
+                self.gen_add_code_line("y[" + str(r) + "] = " + (" + ".join(terms) if terms else "static_cast<T>(0)") + ";")
+            for r in range(3):
+                a, b = cross[r]
+                terms = [C(mass) + "*x[" + str(3 + r) + "]"]
+                if h[a] != 0.0:
+                    terms.append(C(-h[a]) + "*x[" + str(b) + "]")
+                if h[b] != 0.0:
+                    terms.append(C(h[b]) + "*x[" + str(a) + "]")
+                self.gen_add_code_line("y[" + str(3 + r) + "] = " + " + ".join(terms) + ";")
         self.gen_add_end_function()
 
 

@@ -31,6 +31,7 @@ def gen_lds_layout(self):
                        ("T", 48),                     # 6x6 transpose scratch (row stride 8)
                        ("MINV", _pad4(n * n)),        # dense symmetric M^-1 (col*n+row == row*n+col)
                        ("QDD", _pad4(n)),
+                       ("F", 8 * n),                  # wave-uniform link forces parked between the two sweeps of the gradient walk
                        ("OUT", _pad4(2 * n * n))):    # output staging for coalesced stores
         off[name] = cur
         cur += size
