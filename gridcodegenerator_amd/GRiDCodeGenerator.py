@@ -34,13 +34,13 @@ class GRiDCodeGenerator:
         gen_forward_dynamics_inner_function_call, gen_forward_dynamics_inner, gen_forward_dynamics_kernel, \
         gen_forward_dynamics_host, gen_forward_dynamics, \
         gen_inverse_dynamics_gradient_inner_temp_mem_size, gen_inverse_dynamics_gradient_kernel_max_temp_mem_size, \
-        gen_inverse_dynamics_gradient_inner_function_call, gen_inverse_dynamics_gradient_inner, \
+        gen_inverse_dynamics_gradient_inner_function_call, gen_inverse_dynamics_gradient_inner, gen_dc_du_to_lds, \
         gen_inverse_dynamics_gradient_kernel, gen_inverse_dynamics_gradient_host, gen_inverse_dynamics_gradient, \
         gen_forward_dynamics_gradient_inner_temp_mem_size, gen_forward_dynamics_gradient_kernel_max_temp_mem_size, \
         gen_forward_dynamics_gradient_inner_python, gen_forward_dynamics_gradient_device, gen_forward_dynamics_gradient_kernel, \
         gen_forward_dynamics_gradient_host, gen_forward_dynamics_gradient, gen_forward_dynamics_gradient_device_function_call
 
-    def __init__(self, robotObj, DEBUG_MODE=False, NEED_PRINT_MAT=False, USE_DYNAMIC_SHARED_MEM=True, FILE_NAMESPACE="grid"):
+    def __init__(self, robotObj, DEBUG_MODE=False, NEED_PRINT_MAT=False, USE_DYNAMIC_SHARED_MEM=True, FILE_NAMESPACE="grid", COLS_PER_LANE=None):
         self.robot = robotObj
         self.model = DuckRobot(robotObj)  # numeric tables; raises for robots outside the supported joint models
         self.code_str = ""
@@ -52,8 +52,16 @@ class GRiDCodeGenerator:
         n = self.model.n
         if n > 64:
             raise NotImplementedError("robots with more than 64 joints need more than one wavefront per solve")
-        lanes = 8
-        while lanes < n:
+        # COLS_PER_LANE (tuning knob, not in the reference API): 2 -> lane j owns d/dq_j and d/dqd_j (lane group = next pow2 >= n);
+        # 1 -> first half of the group owns the d/dq columns, second half the d/dqd columns (lane group = next pow2 >= 2n)
+        if COLS_PER_LANE is None:
+            COLS_PER_LANE = int(__import__("os").environ.get("GRID_COLS_PER_LANE", "2"))
+        if COLS_PER_LANE == 1 and 2 * n > 64:
+            COLS_PER_LANE = 2
+        self.cols_per_lane = COLS_PER_LANE
+        need = n if COLS_PER_LANE == 2 else 2 * n
+        lanes = 8 if COLS_PER_LANE == 2 else 16
+        while lanes < need:
             lanes *= 2
         self.lanes_per_solve = lanes          # lane j of a group <-> joint j; 6 lanes also carry the articulated inertia columns
         self.suggested_threads = 256
@@ -108,7 +116,7 @@ class GRiDCodeGenerator:
                                  "const int GRID_MAX_SOLVES_PER_BLOCK = SUGGESTED_THREADS/GRID_LANES_PER_SOLVE; // what the *_DYNAMIC_SHARED_MEM_COUNT constants cover",
                                  "// per-solve LDS slice (elements of T) and the offsets of its parts",
                                  "const int GRID_LDS_PER_SOLVE = " + str(lds["TOTAL"]) + ";"])
-        for k in ("IN", "X", "U", "T", "MINV", "QDD", "F", "OUT"):
+        for k in ("IN", "X", "U", "T", "MINV", "QDD", "F", "J", "OUT"):
             self.gen_add_code_line("const int GRID_OFF_" + k + " = " + str(lds[k]) + ";")
         for k in ("ID", "MINV", "FD", "ID_DU", "FD_DU"):
             self.gen_add_code_line("const int " + k + "_DYNAMIC_SHARED_MEM_COUNT = " + str(count) + ";")

@@ -67,12 +67,12 @@ def gen_direct_minv_inner(self, use_thread_group=False):
         self.gen_add_code_line("const T Dinv = static_cast<T>(1)/U[%d];" % s)
         self.gen_add_code_line("if (lane == 0) { s_U[%d] = Dinv; }" % (8 * i + 6))
         self.gen_add_code_line("const T m = ((lane == %d) ? Dinv : static_cast<T>(0)) - Dinv*F_%d[%d];" % (i, i, s))
-        self.gen_add_code_line("Mcol[%d] = m;" % i)
+        self.gen_add_code_line("Mcol[%d] = m; grid_pin(Mcol[%d]);" % (i, i))
         if p != -1:
             self.gen_add_code_line("T X[18]; grid_load_X(X, &s_X[GRID_X_STRIDE*%d]);" % i)
             self.gen_add_code_line("#pragma unroll")
             self.gen_add_code_line("for (int r = 0; r < 6; r++) { F_%d[r] += U[r]*m; }" % i)
-            self.gen_add_code_line("grid_xtmul_peq(F_%d, X, F_%d);" % (p, i))
+            self.gen_add_code_line("grid_xtmul_peq(F_%d, X, F_%d); grid_pin6(F_%d);" % (p, i, p))
             self.gen_add_code_line("// IA_parent += X^T (IA - U Dinv U^T) X, one column per lane, transposed through LDS")
             self.gen_add_code_line("T Ia[6], Tc[6], Tr[6];")
             self.gen_add_code_line("const T w = Dinv*IA_%d[%d];" % (i, s))
@@ -86,7 +86,7 @@ def gen_direct_minv_inner(self, use_thread_group=False):
             self.gen_add_sync(use_thread_group)
             self.gen_add_code_line("#pragma unroll")
             self.gen_add_code_line("for (int r = 0; r < 6; r++) { Tr[r] = s_T[8*cI + r]; }")
-            self.gen_add_code_line("grid_xtmul_peq(IA_%d, X, Tr);" % p)
+            self.gen_add_code_line("grid_xtmul_peq(IA_%d, X, Tr); grid_pin6(IA_%d);" % (p, p))
             self.gen_add_sync(use_thread_group)
         self.gen_add_end_control_flow()
 
@@ -111,7 +111,7 @@ def gen_direct_minv_inner(self, use_thread_group=False):
         self.gen_add_code_line("#pragma unroll")
         self.gen_add_code_line("for (int r = 0; r < 6; r++) { U[r] = s_U[%d + r]; }" % (8 * i))
         self.gen_add_code_line("grid_xmul(Ff_%d, X, Ff_%d);" % (i, p))
-        self.gen_add_code_line("Mcol[%d] -= s_U[%d]*grid_dot6(U, Ff_%d);" % (i, 8 * i + 6, i))
+        self.gen_add_code_line("Mcol[%d] -= s_U[%d]*grid_dot6(U, Ff_%d); grid_pin(Mcol[%d]);" % (i, 8 * i + 6, i, i))
         if has_children:
             self.gen_add_code_line("Ff_%d[%d] += Mcol[%d];" % (i, s, i))
         self.gen_add_end_control_flow()
@@ -145,7 +145,7 @@ def gen_direct_minv_kernel(self, use_thread_group=False, single_call_timing=Fals
     self.gen_add_code_lines(["T *s_q = &s_mem[GRID_OFF_IN];",
                              "T *s_X = &s_mem[GRID_OFF_X]; T *s_U = &s_mem[GRID_OFF_U]; T *s_T = &s_mem[GRID_OFF_T]; T *s_Minv = &s_mem[GRID_OFF_MINV]; T *s_out = &s_mem[GRID_OFF_OUT];"])
     if single_call_timing:
-        self.gen_add_code_line("const int k = 0; const int kc = 0; const bool valid = (blockIdx.x + blockIdx.y == 0) && (grp == 0);")
+        self.gen_add_code_line("const int k = 0; const int kc = 0; const bool valid = (blockIdx.x + blockIdx.y == 0) && (grp == 0); const int lane = lane_id;")
         self.gen_add_code_line("if (!valid) {return;}")
     else:
         self.gen_add_parallel_loop("k", "NUM_TIMESTEPS", use_thread_group, block_level=True)

@@ -30,18 +30,32 @@ def gen_forward_dynamics_gradient_inner_python(self, use_thread_group=False, use
     n = self.model.n
     if not use_qdd_Minv_input:
         self.gen_forward_dynamics_inner_function_call(use_thread_group)  # Minv, c, qdd (v is recomputed below inside the fused gradient walk)
-    self.gen_add_code_line("T dc_dq[%d], dc_dqd[%d];" % (n, n))
+    C = self.cols_per_lane
+    H = self.lanes_per_solve // 2
+    self.gen_add_code_line(("T dc_dq[%d], dc_dqd[%d];" % (n, n)) if C == 2 else ("T dc_du[%d];" % n))
     self.gen_inverse_dynamics_gradient_inner_function_call(use_thread_group)
-    self.gen_add_code_line("// finally df/du = -Minv*dc/du: this lane's two columns (Minv is read wave-uniformly from LDS)")
-    self.gen_add_code_line("if (lane < %d) {" % n, True)
-    self.gen_add_code_line("#pragma unroll")
-    self.gen_add_code_line("for (int row = 0; row < %d; row++) {" % n, True)
-    self.gen_add_code_line("T vq = static_cast<T>(0); T vd = static_cast<T>(0);")
-    self.gen_add_code_line("#pragma unroll")
-    self.gen_add_code_line("for (int i = 0; i < %d; i++) { const T mv = s_Minv[row*%d + i]; vq += mv*dc_dq[i]; vd += mv*dc_dqd[i]; }" % (n, n))
-    self.gen_add_code_line("%s[lane*%d + row] = -vq; %s[%d + lane*%d + row] = -vd;" % (s_df_du_name, n, s_df_du_name, n * n, n))
-    self.gen_add_end_control_flow()
-    self.gen_add_end_control_flow()
+    self.gen_add_code_line("// finally df/du = -Minv*dc/du: this lane's column(s) (Minv is read wave-uniformly from LDS)")
+    if C == 2:
+        self.gen_add_code_line("if (lane < %d) {" % n, True)
+        self.gen_add_code_line("#pragma unroll")
+        self.gen_add_code_line("for (int row = 0; row < %d; row++) {" % n, True)
+        self.gen_add_code_line("T vq = static_cast<T>(0); T vd = static_cast<T>(0);")
+        self.gen_add_code_line("#pragma unroll")
+        self.gen_add_code_line("for (int i = 0; i < %d; i++) { const T mv = s_Minv[row*%d + i]; vq += mv*dc_dq[i]; vd += mv*dc_dqd[i]; }" % (n, n))
+        self.gen_add_code_line("%s[lane*%d + row] = -vq; %s[%d + lane*%d + row] = -vd;" % (s_df_du_name, n, s_df_du_name, n * n, n))
+        self.gen_add_end_control_flow()
+        self.gen_add_end_control_flow()
+    else:
+        self.gen_add_code_line("if ((lane & %d) < %d) {" % (H - 1, n), True)
+        self.gen_add_code_line("const int col = (lane & %d) + ((lane >= %d) ? %d : 0);" % (H - 1, H, n))
+        self.gen_add_code_line("#pragma unroll")
+        self.gen_add_code_line("for (int row = 0; row < %d; row++) {" % n, True)
+        self.gen_add_code_line("T val = static_cast<T>(0);")
+        self.gen_add_code_line("#pragma unroll")
+        self.gen_add_code_line("for (int i = 0; i < %d; i++) { val += s_Minv[row*%d + i]*dc_du[i]; }" % (n, n))
+        self.gen_add_code_line("%s[col*%d + row] = -val;" % (s_df_du_name, n))
+        self.gen_add_end_control_flow()
+        self.gen_add_end_control_flow()
 
 
 def gen_forward_dynamics_gradient_device(self, use_thread_group=False, use_qdd_Minv_input=False):
@@ -66,7 +80,7 @@ def gen_forward_dynamics_gradient_device(self, use_thread_group=False, use_qdd_M
     self.gen_add_code_line("template <typename T>")
     self.gen_add_code_line("__device__ __forceinline__")
     self.gen_add_code_line(func_def, True)
-    self.gen_add_code_line("T *s_X = &s_work[GRID_OFF_X]; T *s_U = &s_work[GRID_OFF_U]; T *s_T = &s_work[GRID_OFF_T]; T *s_F = &s_work[GRID_OFF_F];")
+    self.gen_add_code_line("T *s_X = &s_work[GRID_OFF_X]; T *s_U = &s_work[GRID_OFF_U]; T *s_T = &s_work[GRID_OFF_T]; T *s_F = &s_work[GRID_OFF_F]; T *s_J = &s_work[GRID_OFF_J];")
     if not use_qdd_Minv_input:
         self.gen_add_code_line("T *s_Minv = &s_work[GRID_OFF_MINV]; T *s_qdd = &s_work[GRID_OFF_QDD];")
     self.gen_add_code_line("(void)s_U; (void)s_T;")
@@ -105,10 +119,10 @@ def gen_forward_dynamics_gradient_kernel(self, use_thread_group=False, use_qdd_M
         self.gen_add_code_line("T *s_q_qd = &s_mem[GRID_OFF_IN]; T *s_q = s_q_qd; T *s_qd = &s_q_qd[%d]; T *s_qdd = &s_mem[GRID_OFF_QDD];" % n)
     else:
         self.gen_add_code_line("T *s_q_qd_u = &s_mem[GRID_OFF_IN]; T *s_q = s_q_qd_u; T *s_qd = &s_q_qd_u[%d]; T *s_u = &s_q_qd_u[%d]; T *s_qdd = &s_mem[GRID_OFF_QDD];" % (n, 2 * n))
-    self.gen_add_code_line("T *s_X = &s_mem[GRID_OFF_X]; T *s_U = &s_mem[GRID_OFF_U]; T *s_T = &s_mem[GRID_OFF_T]; T *s_Minv = &s_mem[GRID_OFF_MINV]; T *s_F = &s_mem[GRID_OFF_F]; T *s_df_du = &s_mem[GRID_OFF_OUT];")
+    self.gen_add_code_line("T *s_X = &s_mem[GRID_OFF_X]; T *s_U = &s_mem[GRID_OFF_U]; T *s_T = &s_mem[GRID_OFF_T]; T *s_Minv = &s_mem[GRID_OFF_MINV]; T *s_F = &s_mem[GRID_OFF_F]; T *s_J = &s_mem[GRID_OFF_J]; T *s_df_du = &s_mem[GRID_OFF_OUT];")
     self.gen_add_code_line("(void)s_U; (void)s_T;")
     if single_call_timing:
-        self.gen_add_code_line("const int k = 0; const int kc = 0; const bool valid = (blockIdx.x + blockIdx.y == 0) && (grp == 0);")
+        self.gen_add_code_line("const int k = 0; const int kc = 0; const bool valid = (blockIdx.x + blockIdx.y == 0) && (grp == 0); const int lane = lane_id;")
         self.gen_add_code_line("if (!valid) {return;}")
     else:
         self.gen_add_parallel_loop("k", "NUM_TIMESTEPS", use_thread_group, block_level=True)

@@ -72,15 +72,15 @@ def gen_inverse_dynamics_inner(self, use_thread_group=False, use_qdd_input=False
             self.gen_add_code_line("grid_xmul(a_%d, X, a_%d); grid_mxS_peq<T,%d>(a_%d, v_%d, qd_%d);" % (i, p, s, i, i, i))
         if use_qdd_input:
             self.gen_add_code_line("a_%d[%d] += s_qdd[%d];" % (i, s, i))
-        self.gen_add_code_line("T Iv[6]; grid_imul_%d(Iv, v_%d); grid_imul_%d(f_%d, a_%d); grid_fxv_peq(f_%d, v_%d, Iv);" % (i, i, i, i, i, i, i))
+        self.gen_add_code_line("T Iv[6]; grid_imul_%d(Iv, v_%d); grid_imul_%d(f_%d, a_%d); grid_fxv_peq(f_%d, v_%d, Iv); grid_pin6(f_%d);" % (i, i, i, i, i, i, i, i))
         self.gen_add_end_control_flow()
 
     def post(i):
         s, p = m.S_index[i], m.parent[i]
         damp = m.damping[i]
-        self.gen_add_code_line("c[%d] = f_%d[%d]%s;" % (i, i, s, (" + static_cast<T>(" + repr(float(damp)) + ")*qd_" + str(i)) if damp != 0.0 else ""))
+        self.gen_add_code_line("c[%d] = f_%d[%d]%s; grid_pin(c[%d]);" % (i, i, s, (" + static_cast<T>(" + repr(float(damp)) + ")*qd_" + str(i)) if damp != 0.0 else "", i))
         if p != -1:
-            self.gen_add_code_line("{ T X[18]; grid_load_X(X, &s_X[GRID_X_STRIDE*%d]); grid_xtmul_peq(f_%d, X, f_%d); }" % (i, p, i))
+            self.gen_add_code_line("{ T X[18]; grid_load_X(X, &s_X[GRID_X_STRIDE*%d]); grid_xtmul_peq(f_%d, X, f_%d); grid_pin6(f_%d); }" % (i, p, i, p))
 
     self.gen_tree_traversal(pre, post)
     self.gen_add_end_function()
@@ -108,7 +108,7 @@ def gen_inverse_dynamics_kernel(self, use_thread_group=False, use_qdd_input=Fals
     self.gen_add_code_lines(["T *s_q_qd = &s_mem[GRID_OFF_IN]; T *s_q = s_q_qd; T *s_qd = &s_q_qd[%d]; T *s_qdd = &s_q_qd[%d];" % (n, 2 * n),
                              "T *s_X = &s_mem[GRID_OFF_X]; T *s_c = &s_mem[GRID_OFF_OUT];"])
     if single_call_timing:
-        self.gen_add_code_line("const int k = 0; const int kc = 0; const bool valid = (blockIdx.x + blockIdx.y == 0) && (grp == 0);")
+        self.gen_add_code_line("const int k = 0; const int kc = 0; const bool valid = (blockIdx.x + blockIdx.y == 0) && (grp == 0); const int lane = lane_id;")
         self.gen_add_code_line("if (!valid) {return;}")
     else:
         self.gen_add_parallel_loop("k", "NUM_TIMESTEPS", use_thread_group, block_level=True)

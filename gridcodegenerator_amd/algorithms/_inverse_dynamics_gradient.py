@@ -4,19 +4,28 @@ Mirrors the role of the reference's algorithms/_inverse_dynamics_gradient.py (ge
 :27-775, device :777, kernel :817, host :890) and follows the reference oracle /root/reference/_test.py:229-494
 (test_rnea_grad_inner; Carpentier & Mansard, "Analytical Derivatives of Rigid Body Dynamics Algorithms").
 
-Lane mapping: lane j of the solve's lane group owns the two derivative columns d/dq_j and d/dqd_j of every link
-quantity (dv, da, df), as register 6-vectors.  A column is structurally zero at link i unless j is an ancestor of i,
-i itself (forward sweep) or in i's subtree (after the backward sweep), and zeros propagate through the linear
-recursions, so the reference's sparsity-compressed column bookkeeping (helpers/_topology_helpers.py:515-542,
-_inverse_dynamics_gradient.py:597-651,731-760) and its shared-memory atomics (:653-655) are not needed.
-The wave-uniform link quantities (v, a, f, I v) are recomputed in registers inside the same depth-first walk
-(this is the RNEA-with-qdd pass a7 of SURVEY.md section 8(a)), and the forward and backward sweeps of the derivative
-are fused into that one walk, so only O(depth) link vectors are live.
+Lane mapping.  Each lane of the solve's lane group owns derivative COLUMNS of every link quantity (dv, da, df) as register
+6-vectors: with COLS_PER_LANE == 2 lane j owns d/dq_j and d/dqd_j; with COLS_PER_LANE == 1 the first half of the group
+owns the d/dq columns and the second half the d/dqd columns.  A column is structurally zero at link k unless its joint is
+an ancestor of k or k itself, and zeros propagate through the linear recursions, so the reference's sparsity-compressed
+column bookkeeping (helpers/_topology_helpers.py:515-542, _inverse_dynamics_gradient.py:597-651,731-760) and its
+shared-memory atomics (:653-655) are not needed.
+
+Register budget.  The oracle's backward sweep (df_parent += X^T df, _test.py:450-470) needs every link's df until the walk
+returns - 12 VGPRs per tree level and lane, which spilled to scratch on gfx950.  Instead the extraction
+dc[a][col] = S_a^T sum_{k in subtree(a)} (kX_a)^T df_k[col] is evaluated as sum_k J_{k,a} . df_k[col] during the FORWARD walk,
+where J_{k,a} = kX_a S_a is exactly the d/dqd_a column of dv_k that the lane owning that column already holds: it is
+published through LDS and every lane dots it with its own transient df_k.  Only the single-vector correction
+-X^T mxS(S, f_subtree) of column == joint (_test.py:431-440,469-470) still travels up the tree in a light backward sweep.
+
+The wave-uniform link quantities (v, a, f, I v) of the RNEA pass with qdd are recomputed in
+registers inside the same depth-first walk; the link forces are parked in LDS between the two sweeps.
 
 Identities used (checked against the oracle by the tests):
   * mxS(S_i, X_i v_parent) == mxS(S_i, v_i)    because v_i = X_i v_parent + S_i qd_i and S_i x S_i = 0
     (the oracle's MxXv, _test.py:308, therefore equals its Mxv, :310; both vanish for root joints);
-  * (fx(v) I) dv == fx(v) (I dv)               (the oracle materialises FxvI = fx(v) I, _test.py:403).
+  * (fx(v) I) dv == fx(v) (I dv)               (the oracle materialises FxvI = fx(v) I, _test.py:403);
+  * d v_k / d qd_a == kX_a S_a                  (velocity Jacobian column).
 """
 
 
@@ -29,85 +38,148 @@ def gen_inverse_dynamics_gradient_kernel_max_temp_mem_size(self):
 
 
 def gen_inverse_dynamics_gradient_inner_function_call(self, use_thread_group=False, updated_var_names=None):
-    self.gen_add_code_line("inverse_dynamics_gradient_inner<T>(dc_dq, dc_dqd, s_qd, s_qdd, s_X, s_F, gravity, lane);")
+    if self.cols_per_lane == 2:
+        self.gen_add_code_line("inverse_dynamics_gradient_inner<T>(dc_dq, dc_dqd, s_qd, s_qdd, s_X, s_F, s_J, gravity, lane);")
+    else:
+        self.gen_add_code_line("inverse_dynamics_gradient_inner<T>(dc_du, s_qd, s_qdd, s_X, s_F, s_J, gravity, lane);")
 
 
 def gen_inverse_dynamics_gradient_inner(self, use_thread_group=False):
     m = self.model
     n = m.n
-    self.gen_add_func_doc("Computes the gradient of inverse dynamics (this lane's two columns)",
-                          ["dc_dq[i] = d c_i / d q_lane and dc_dqd[i] = d c_i / d qd_lane for i = 0..n-1 (zero for lanes >= n)",
-                           "v, a, f of the RNEA pass with qdd are recomputed wave-uniformly inside the same tree walk",
-                           "follows /root/reference/_test.py:229-494 incl. the damping term on diag(dc/dqd)"],
-                          ["dc_dq, dc_dqd are the register outputs", "s_qd is the vector of joint velocities in LDS",
+    C = self.cols_per_lane
+    H = self.lanes_per_solve // 2
+    cols = ("q", "d") if C == 2 else ("u",)  # register name suffixes of the column(s) a lane owns
+    notes = ["v, a, f of the RNEA pass with qdd are recomputed wave-uniformly inside the same tree walk",
+             "follows /root/reference/_test.py:229-494 incl. the damping term on diag(dc/dqd)"]
+    if C == 2:
+        notes.insert(0, "dc_dq[i] = d c_i / d q_lane and dc_dqd[i] = d c_i / d qd_lane for i = 0..n-1 (zero for lanes >= n)")
+        outs = "T (&dc_dq)[%d], T (&dc_dqd)[%d]" % (n, n)
+    else:
+        notes.insert(0, "dc_du[i] = d c_i / d q_lane for lanes < %d and d c_i / d qd_(lane-%d) for lanes >= %d" % (H, H, H))
+        outs = "T (&dc_du)[%d]" % n
+    self.gen_add_func_doc("Computes the gradient of inverse dynamics (this lane's column(s))", notes,
+                          ["dc_* are the register outputs", "s_qd is the vector of joint velocities in LDS",
                            "s_qdd is the vector of joint accelerations in LDS", "s_X is this solve's compact X(q) storage",
-                           "s_F is LDS scratch for the wave-uniform link forces (8 floats per joint)", "gravity is the gravity constant", "lane is the caller's lane index inside the solve's lane group"], None)
+                           "s_F is LDS scratch for the wave-uniform link forces (8 floats per joint)",
+                           "s_J is LDS scratch for the velocity Jacobian columns of the current link (8 floats per joint)",
+                           "gravity is the gravity constant", "lane is the caller's lane index inside the solve's lane group"], None)
     self.gen_add_code_line("template <typename T>")
     self.gen_add_code_line("__device__ __forceinline__")
-    self.gen_add_code_line("void inverse_dynamics_gradient_inner(T (&dc_dq)[%d], T (&dc_dqd)[%d], const T *s_qd, const T *s_qdd, const T *s_X, T *s_F, const T gravity, const int lane) {" % (n, n), True)
+    self.gen_add_code_line("void inverse_dynamics_gradient_inner(" + outs + ", const T *s_qd, const T *s_qdd, const T *s_X, T *s_F, T *s_J, const T gravity, const int lane) {", True)
+    ZERO, ONE = "static_cast<T>(0)", "static_cast<T>(1)"
+    if C == 2:
+        self.gen_add_code_line("const int jcol = lane; // joint whose two columns this lane owns")
+        dcs = {"q": "dc_dq", "d": "dc_dqd"}
+    else:
+        self.gen_add_code_line("const int jcol = lane & %d; const bool is_qd = lane >= %d; // column owned by this lane" % (H - 1, H))
+        dcs = {"u": "dc_du"}
+    self.gen_add_code_line("#pragma unroll")
+    self.gen_add_code_line("for (int i = 0; i < %d; i++) { %s }" % (n, " ".join(d + "[i] = " + ZERO + ";" for d in dcs.values())))
 
-    def pre(i):
-        s, p = m.S_index[i], m.parent[i]
-        I = str(i)
-        P = str(p)
-        self.gen_add_code_line("const T self_" + I + " = (lane == " + I + ") ? static_cast<T>(1) : static_cast<T>(0);")
-        self.gen_add_code_line("T v_%s[6], a_%s[6], dvq_%s[6], dvd_%s[6], daq_%s[6], dad_%s[6], dfq_%s[6], dfd_%s[6];" % ((I,) * 8))
+    def pre(k):
+        s, p = m.S_index[k], m.parent[k]
+        K, P = str(k), str(p)
+        if C == 2:
+            self.gen_add_code_line("const T self_%s = (jcol == %s) ? %s : %s;" % (K, K, ONE, ZERO))
+            selq, seld = "self_" + K, "self_" + K
+        else:
+            self.gen_add_code_line("const T selq_%s = (jcol == %s && !is_qd) ? %s : %s; const T seld_%s = (jcol == %s && is_qd) ? %s : %s;" % (K, K, ONE, ZERO, K, K, ONE, ZERO))
+            selq, seld = "selq_" + K, "seld_" + K
+        decl = ["v_%s[6]" % K, "a_%s[6]" % K, "w_%s[6]" % K]
+        for c in cols:
+            decl += ["dv%s_%s[6]" % (c, K), "da%s_%s[6]" % (c, K)]
+        self.gen_add_code_line("T " + ", ".join(decl) + ";")
+        self.gen_add_code_line("grid_zero6(w_%s);" % K)
         self.gen_add_code_line("{", True)
-        self.gen_add_code_line("T X[18]; grid_load_X(X, &s_X[GRID_X_STRIDE*" + I + "]);")
-        self.gen_add_code_line("const T qd = s_qd[" + I + "]; const T qdd = s_qdd[" + I + "];")
+        self.gen_add_code_line("T X[18]; grid_load_X(X, &s_X[GRID_X_STRIDE*" + K + "]);")
+        self.gen_add_code_line("const T qd = s_qd[" + K + "]; const T qdd = s_qdd[" + K + "];")
         self.gen_add_code_line("// wave-uniform link quantities (RNEA with qdd)")
         self.gen_add_code_line("T Xa[6], Mxv[6], MxXa[6], Iv[6];")
         if p == -1:
-            self.gen_add_code_line("grid_zero6(v_%s); v_%s[%d] = qd;" % (I, I, s))
+            self.gen_add_code_line("grid_zero6(v_%s); v_%s[%d] = qd;" % (K, K, s))
             self.gen_add_code_line("grid_zero6(Xa); Xa[3] = X[2]*gravity; Xa[4] = X[5]*gravity; Xa[5] = X[8]*gravity;")
         else:
-            self.gen_add_code_line("grid_xmul(v_%s, X, v_%s); v_%s[%d] += qd;" % (I, P, I, s))
+            self.gen_add_code_line("grid_xmul(v_%s, X, v_%s); v_%s[%d] += qd;" % (K, P, K, s))
             self.gen_add_code_line("grid_xmul(Xa, X, a_%s);" % P)
-        self.gen_add_code_line("grid_zero6(Mxv); grid_mxS_peq<T,%d>(Mxv, v_%s, static_cast<T>(1));" % (s, I))
-        self.gen_add_code_line("grid_zero6(MxXa); grid_mxS_peq<T,%d>(MxXa, Xa, static_cast<T>(1));" % s)
+        self.gen_add_code_line("grid_zero6(Mxv); grid_mxS_peq<T,%d>(Mxv, v_%s, %s);" % (s, K, ONE))
+        self.gen_add_code_line("grid_zero6(MxXa); grid_mxS_peq<T,%d>(MxXa, Xa, %s);" % (s, ONE))
         self.gen_add_code_line("#pragma unroll")
-        self.gen_add_code_line("for (int r = 0; r < 6; r++) { a_%s[r] = Xa[r] + Mxv[r]*qd; }" % I)
-        self.gen_add_code_line("a_%s[%d] += qdd;" % (I, s))
-        self.gen_add_code_line("// the link force is wave-uniform and only needed again on the way back up: park it in LDS instead of 6 VGPRs per level")
-        self.gen_add_code_line("{ T f[6]; grid_imul_%s(Iv, v_%s); grid_imul_%s(f, a_%s); grid_fxv_peq(f, v_%s, Iv);" % (I, I, I, I, I))
+        self.gen_add_code_line("for (int r = 0; r < 6; r++) { a_%s[r] = Xa[r] + Mxv[r]*qd; }" % K)
+        self.gen_add_code_line("a_%s[%d] += qdd;" % (K, s))
+        self.gen_add_code_line("// the link force is wave-uniform and only needed again on the way back up: park it in LDS")
+        self.gen_add_code_line("{ T f[6]; grid_imul_%s(Iv, v_%s); grid_imul_%s(f, a_%s); grid_fxv_peq(f, v_%s, Iv);" % (K, K, K, K, K))
         self.gen_add_code_line("  if (lane == 0) {")
         self.gen_add_code_line("      #pragma unroll")
-        self.gen_add_code_line("      for (int r = 0; r < 6; r++) { s_F[%d + r] = f[r]; }" % (8 * i))
+        self.gen_add_code_line("      for (int r = 0; r < 6; r++) { s_F[%d + r] = f[r]; }" % (8 * k))
         self.gen_add_code_line("  } }")
-        self.gen_add_code_line("// this lane's columns: dv, da (forward recursions with the self terms of column == joint)")
-        if p == -1:
-            self.gen_add_code_line("#pragma unroll")
-            self.gen_add_code_line("for (int r = 0; r < 6; r++) { dvq_%s[r] = self_%s*Mxv[r]; dvd_%s[r] = static_cast<T>(0); daq_%s[r] = self_%s*MxXa[r]; dad_%s[r] = self_%s*Mxv[r]; }" % (I, I, I, I, I, I, I))
-            self.gen_add_code_line("dvd_%s[%d] = self_%s;" % (I, s, I))
+        self.gen_add_code_line("// this lane's column(s): dv, da (forward recursions with the self terms of column == joint)")
+        if C == 2:
+            if p == -1:
+                self.gen_add_code_line("#pragma unroll")
+                self.gen_add_code_line("for (int r = 0; r < 6; r++) { dvq_%s[r] = %s*Mxv[r]; dvd_%s[r] = %s; daq_%s[r] = %s*MxXa[r]; dad_%s[r] = %s*Mxv[r]; }" % (K, selq, K, ZERO, K, selq, K, seld))
+                self.gen_add_code_line("dvd_%s[%d] = %s;" % (K, s, seld))
+            else:
+                self.gen_add_code_line("grid_xmul(dvq_%s, X, dvq_%s); grid_xmul(dvd_%s, X, dvd_%s);" % (K, P, K, P))
+                self.gen_add_code_line("grid_xmul(daq_%s, X, daq_%s); grid_xmul(dad_%s, X, dad_%s);" % (K, P, K, P))
+                self.gen_add_code_line("#pragma unroll")
+                self.gen_add_code_line("for (int r = 0; r < 6; r++) { dvq_%s[r] += %s*Mxv[r]; daq_%s[r] += %s*MxXa[r]; dad_%s[r] += %s*Mxv[r]; }" % (K, selq, K, selq, K, seld))
+                self.gen_add_code_line("dvd_%s[%d] += %s;" % (K, s, seld))
+            self.gen_add_code_line("grid_mxS_peq<T,%d>(daq_%s, dvq_%s, qd); grid_mxS_peq<T,%d>(dad_%s, dvd_%s, qd);" % (s, K, K, s, K, K))
         else:
-            self.gen_add_code_line("grid_xmul(dvq_%s, X, dvq_%s); grid_xmul(dvd_%s, X, dvd_%s);" % (I, P, I, P))
-            self.gen_add_code_line("grid_xmul(daq_%s, X, daq_%s); grid_xmul(dad_%s, X, dad_%s);" % (I, P, I, P))
+            if p == -1:
+                self.gen_add_code_line("#pragma unroll")
+                self.gen_add_code_line("for (int r = 0; r < 6; r++) { dvu_%s[r] = %s*Mxv[r]; dau_%s[r] = %s*MxXa[r] + %s*Mxv[r]; }" % (K, selq, K, selq, seld))
+                self.gen_add_code_line("dvu_%s[%d] += %s;" % (K, s, seld))
+            else:
+                self.gen_add_code_line("grid_xmul(dvu_%s, X, dvu_%s); grid_xmul(dau_%s, X, dau_%s);" % (K, P, K, P))
+                self.gen_add_code_line("#pragma unroll")
+                self.gen_add_code_line("for (int r = 0; r < 6; r++) { dvu_%s[r] += %s*Mxv[r]; dau_%s[r] += %s*MxXa[r] + %s*Mxv[r]; }" % (K, selq, K, selq, seld))
+                self.gen_add_code_line("dvu_%s[%d] += %s;" % (K, s, seld))
+            self.gen_add_code_line("grid_mxS_peq<T,%d>(dau_%s, dvu_%s, qd);" % (s, K, K))
+        self.gen_add_code_line("// publish the velocity Jacobian columns J_{k,a} = d v_k / d qd_a (the d/dqd columns of dv)")
+        if C == 2:
+            self.gen_add_code_line("if (lane < %d) {" % n, True)
             self.gen_add_code_line("#pragma unroll")
-            self.gen_add_code_line("for (int r = 0; r < 6; r++) { dvq_%s[r] += self_%s*Mxv[r]; daq_%s[r] += self_%s*MxXa[r]; dad_%s[r] += self_%s*Mxv[r]; }" % (I, I, I, I, I, I))
-            self.gen_add_code_line("dvd_%s[%d] += self_%s;" % (I, s, I))
-        self.gen_add_code_line("grid_mxS_peq<T,%d>(daq_%s, dvq_%s, qd); grid_mxS_peq<T,%d>(dad_%s, dvd_%s, qd);" % (s, I, I, s, I, I))
-        self.gen_add_code_line("// df = I da + fx(dv) (I v) + fx(v) (I dv)")
-        self.gen_add_code_line("{ T Idv[6]; grid_imul_%s(dfq_%s, daq_%s); grid_fxv_peq(dfq_%s, dvq_%s, Iv); grid_imul_%s(Idv, dvq_%s); grid_fxv_peq(dfq_%s, v_%s, Idv); }" % (I, I, I, I, I, I, I, I, I))
-        self.gen_add_code_line("{ T Idv[6]; grid_imul_%s(dfd_%s, dad_%s); grid_fxv_peq(dfd_%s, dvd_%s, Iv); grid_imul_%s(Idv, dvd_%s); grid_fxv_peq(dfd_%s, v_%s, Idv); }" % (I, I, I, I, I, I, I, I, I))
+            self.gen_add_code_line("for (int r = 0; r < 6; r++) { s_J[8*lane + r] = dvd_%s[r]; }" % K)
+        else:
+            self.gen_add_code_line("if (is_qd) {", True)
+            self.gen_add_code_line("#pragma unroll")
+            self.gen_add_code_line("for (int r = 0; r < 6; r++) { s_J[8*jcol + r] = dvu_%s[r]; }" % K)
+        self.gen_add_end_control_flow()
+        self.gen_add_code_line("// local df = I da + fx(dv) (I v) + fx(v) (I dv), consumed at once: dc[a] += J_{k,a} . df for a in ancestors(k) + {k}")
+        for c in cols:
+            self.gen_add_code_line("T df%s[6]; { T Idv[6]; grid_imul_%s(df%s, da%s_%s); grid_fxv_peq(df%s, dv%s_%s, Iv); grid_imul_%s(Idv, dv%s_%s); grid_fxv_peq(df%s, v_%s, Idv); }" % (c, K, c, c, K, c, c, K, K, c, K, c, K))
+        self.gen_add_sync(use_thread_group)
+        for a in m.ancestors[k] + [k]:
+            self.gen_add_code_line("{ T J[6];")
+            self.gen_add_code_line("  #pragma unroll")
+            self.gen_add_code_line("  for (int r = 0; r < 6; r++) { J[r] = s_J[%d + r]; }" % (8 * a))
+            self.gen_add_code_line("  " + " ".join("%s[%d] += grid_dot6(J, df%s); grid_pin(%s[%d]);" % (dcs[c], a, c, dcs[c], a) for c in cols) + " }")
+        self.gen_add_sync(use_thread_group)  # s_J is rewritten by the next link
         self.gen_add_end_control_flow()
 
-    def post(i):
-        s, p = m.S_index[i], m.parent[i]
-        I = str(i)
-        P = str(p)
-        damp = m.damping[i]
-        self.gen_add_code_line("dc_dq[%s] = dfq_%s[%d];" % (I, I, s))
-        self.gen_add_code_line("dc_dqd[%s] = dfd_%s[%d]%s;" % (I, I, s, (" + self_" + I + "*static_cast<T>(" + repr(float(damp)) + ")") if damp != 0.0 else ""))
+    def post(k):
+        s, p = m.S_index[k], m.parent[k]
+        K, P = str(k), str(p)
+        damp = m.damping[k]
+        qcol = "q" if C == 2 else "u"
+        selq = ("self_" if C == 2 else "selq_") + K
+        seld = ("self_" if C == 2 else "seld_") + K
+        self.gen_add_code_line("// corrections that travelled up from the subtree: dc[k][col] -= S_k^T w")
+        self.gen_add_code_line("%s[%s] -= w_%s[%d];" % (dcs[qcol], K, K, s))
+        if damp != 0.0:
+            self.gen_add_code_line("%s[%s] += %s*static_cast<T>(%s);" % (dcs["d" if C == 2 else "u"], K, seld, repr(float(damp))))
         if p != -1:
             self.gen_add_sync(use_thread_group)
             self.gen_add_code_line("{", True)
-            self.gen_add_code_line("T X[18]; grid_load_X(X, &s_X[GRID_X_STRIDE*" + I + "]);")
+            self.gen_add_code_line("T X[18]; grid_load_X(X, &s_X[GRID_X_STRIDE*" + K + "]);")
             self.gen_add_code_line("T f[6], fp[6];")
             self.gen_add_code_line("#pragma unroll")
-            self.gen_add_code_line("for (int r = 0; r < 6; r++) { f[r] = s_F[%d + r]; fp[r] = s_F[%d + r]; }" % (8 * i, 8 * p))
-            self.gen_add_code_line("// column == joint picks up -X^T mxS(f) where f is the accumulated subtree force")
-            self.gen_add_code_line("grid_mxS_peq<T,%d>(dfq_%s, f, -self_%s);" % (s, I, I))
-            self.gen_add_code_line("grid_xtmul_peq(fp, X, f); grid_xtmul_peq(dfq_%s, X, dfq_%s); grid_xtmul_peq(dfd_%s, X, dfd_%s);" % (P, I, P, I))
+            self.gen_add_code_line("for (int r = 0; r < 6; r++) { f[r] = s_F[%d + r]; fp[r] = s_F[%d + r]; }" % (8 * k, 8 * p))
+            self.gen_add_code_line("// column == joint injects mxS(S, f_subtree); everything is carried to the parent frame")
+            self.gen_add_code_line("grid_mxS_peq<T,%d>(w_%s, f, %s);" % (s, K, selq))
+            self.gen_add_code_line("grid_xtmul_peq(fp, X, f); grid_xtmul_peq(w_%s, X, w_%s); grid_pin6(w_%s);" % (P, K, P))
             self.gen_add_code_line("if (lane == 0) {", True)
             self.gen_add_code_line("#pragma unroll")
             self.gen_add_code_line("for (int r = 0; r < 6; r++) { s_F[%d + r] = fp[r]; }" % (8 * p))
@@ -116,6 +188,24 @@ def gen_inverse_dynamics_gradient_inner(self, use_thread_group=False):
 
     self.gen_tree_traversal(pre, post)
     self.gen_add_end_function()
+
+
+def gen_dc_du_to_lds(self, dst="s_dc_du", negate_minv=None):
+    """Emits the register -> LDS staging of this lane's column(s) in the device layout [col*n + row]."""
+    n = self.model.n
+    C = self.cols_per_lane
+    H = self.lanes_per_solve // 2
+    if C == 2:
+        self.gen_add_code_line("if (lane < %d) {" % n, True)
+        self.gen_add_code_line("#pragma unroll")
+        self.gen_add_code_line("for (int row = 0; row < %d; row++) { %s[lane*%d + row] = dc_dq[row]; %s[%d + lane*%d + row] = dc_dqd[row]; }" % (n, dst, n, dst, n * n, n))
+        self.gen_add_end_control_flow()
+    else:
+        self.gen_add_code_line("if ((lane & %d) < %d) {" % (H - 1, n), True)
+        self.gen_add_code_line("const int col = (lane & %d) + ((lane >= %d) ? %d : 0);" % (H - 1, H, n))
+        self.gen_add_code_line("#pragma unroll")
+        self.gen_add_code_line("for (int row = 0; row < %d; row++) { %s[col*%d + row] = dc_du[row]; }" % (n, dst, n))
+        self.gen_add_end_control_flow()
 
 
 def gen_inverse_dynamics_gradient_kernel(self, use_thread_group=False, use_qdd_input=False, single_call_timing=False):
@@ -138,9 +228,9 @@ def gen_inverse_dynamics_gradient_kernel(self, use_thread_group=False, use_qdd_i
     self.gen_add_code_line(func_def, True)
     self.gen_kernel_prologue("GRID_LDS_PER_SOLVE")
     self.gen_add_code_lines(["T *s_q_qd = &s_mem[GRID_OFF_IN]; T *s_q = s_q_qd; T *s_qd = &s_q_qd[%d]; T *s_qdd = &s_q_qd[%d];" % (n, 2 * n),
-                             "T *s_X = &s_mem[GRID_OFF_X]; T *s_F = &s_mem[GRID_OFF_F]; T *s_dc_du = &s_mem[GRID_OFF_OUT];"])
+                             "T *s_X = &s_mem[GRID_OFF_X]; T *s_F = &s_mem[GRID_OFF_F]; T *s_J = &s_mem[GRID_OFF_J]; T *s_dc_du = &s_mem[GRID_OFF_OUT];"])
     if single_call_timing:
-        self.gen_add_code_line("const int k = 0; const int kc = 0; const bool valid = (blockIdx.x + blockIdx.y == 0) && (grp == 0);")
+        self.gen_add_code_line("const int k = 0; const int kc = 0; const bool valid = (blockIdx.x + blockIdx.y == 0) && (grp == 0); const int lane = lane_id;")
         self.gen_add_code_line("if (!valid) {return;}")
     else:
         self.gen_add_parallel_loop("k", "NUM_TIMESTEPS", use_thread_group, block_level=True)
@@ -153,12 +243,9 @@ def gen_inverse_dynamics_gradient_kernel(self, use_thread_group=False, use_qdd_i
         self.gen_add_code_line("for (int rep = 0; rep < NUM_TIMESTEPS; rep++){", True)
     self.gen_add_code_line("// compute")
     self.gen_load_update_XImats_helpers_function_call(use_thread_group)
-    self.gen_add_code_line("T dc_dq[%d], dc_dqd[%d];" % (n, n))
+    self.gen_add_code_line(("T dc_dq[%d], dc_dqd[%d];" % (n, n)) if self.cols_per_lane == 2 else ("T dc_du[%d];" % n))
     self.gen_inverse_dynamics_gradient_inner_function_call(use_thread_group)
-    self.gen_add_code_line("if (lane < %d) {" % n, True)
-    self.gen_add_code_line("#pragma unroll")
-    self.gen_add_code_line("for (int row = 0; row < %d; row++) { s_dc_du[lane*%d + row] = dc_dq[row]; s_dc_du[%d + lane*%d + row] = dc_dqd[row]; }" % (n, n, n * n, n))
-    self.gen_add_end_control_flow()
+    self.gen_dc_du_to_lds("s_dc_du")
     if single_call_timing:
         self.gen_add_end_control_flow()
     self.gen_kernel_save_result("dc_du", 2 * n * n, 2 * n * n, use_thread_group)

@@ -61,6 +61,7 @@ def gen_add_parallel_loop(self, var_name, max_val, use_thread_group=False, block
                                "; " + var_name + "0 += gridDim.x*gridDim.y*gpb){", True)
         self.gen_add_code_line("const int " + var_name + " = " + var_name + "0 + grp; const bool valid = " + var_name + " < " + max_val +
                                "; const int " + var_name + "c = valid ? " + var_name + " : " + max_val + " - 1;")
+        self.gen_add_code_line("const int lane = grid_loop_variant(lane_id); // keeps lane-dependent values from being hoisted out of the batch loop (and spilled)")
     else:
         self.gen_add_code_line("for(int " + var_name + " = lane; " + var_name + " < " + max_val + "; " + var_name +
                                " += GRID_LANES_PER_SOLVE){", True)
@@ -96,7 +97,7 @@ def gen_kernel_prologue(self, lds_per_solve_const):
     GRID_MAX_SOLVES_PER_BLOCK groups, which is what the *_DYNAMIC_SHARED_MEM_COUNT constants are sized for) retire."""
     self.gen_add_code_lines([
         "const int tid = threadIdx.x + threadIdx.y*blockDim.x;",
-        "const int lane = tid & (GRID_LANES_PER_SOLVE-1); // lane j of a solve's lane group owns joint j",
+        "const int lane_id = tid & (GRID_LANES_PER_SOLVE-1); // lane j of a solve's lane group owns joint j",
         "const int grp = tid / GRID_LANES_PER_SOLVE;",
         "int gpb = (blockDim.x*blockDim.y) / GRID_LANES_PER_SOLVE; if (gpb > GRID_MAX_SOLVES_PER_BLOCK) {gpb = GRID_MAX_SOLVES_PER_BLOCK;}",
         "if (grp >= gpb) {return;}",

@@ -19,6 +19,25 @@ __device__ __forceinline__ void grid_wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// Returns x unchanged but opaque to the optimizer: used once per batch-loop iteration on the lane index so that
+// lane-dependent (loop-invariant) values are recomputed per iteration instead of being hoisted and kept live - on gfx950 the
+// hoisted values of a 5k-instruction loop body ended up in scratch.
+__device__ __forceinline__ int grid_loop_variant(int x) {
+    asm volatile("" : "+v"(x));
+    return x;
+}
+
+// Pins a value (or 6-vector) in registers at this point of the program.  Without it LLVM sinks whole dependency chains
+// (thousands of FMAs) down into the final `if (lane < n)` store block because that is their only use: the LDS loads that feed
+// them have to stay above the wave-level syncs, so everything loaded in between was spilled to scratch.
+template <typename T>
+__device__ __forceinline__ void grid_pin(T &x) { asm volatile("" : "+v"(x)); }
+template <typename T>
+__device__ __forceinline__ void grid_pin6(T (&v)[6]) {
+    #pragma unroll
+    for (int r = 0; r < 6; r++) { asm volatile("" : "+v"(v[r])); }
+}
+
 // X is stored compactly per joint: X[0..8] = E (row-major 3x3, top-left == bottom-right block),
 // X[9..17] = B (bottom-left block); the top-right block is identically zero.
 #define GRID_X_STRIDE 20  // floats per joint in LDS (18 used; keeps every joint 16-byte aligned)

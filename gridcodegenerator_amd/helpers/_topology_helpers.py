@@ -32,6 +32,7 @@ def gen_lds_layout(self):
                        ("MINV", _pad4(n * n)),        # dense symmetric M^-1 (col*n+row == row*n+col)
                        ("QDD", _pad4(n)),
                        ("F", 8 * n),                  # wave-uniform link forces parked between the two sweeps of the gradient walk
+                       ("J", 8 * n),                  # velocity Jacobian columns of the current link (published by the d/dqd lanes)
                        ("OUT", _pad4(2 * n * n))):    # output staging for coalesced stores
         off[name] = cur
         cur += size
