@@ -68,6 +68,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--threads", type=int, default=0, help="threads per block override (0 = library default)")
     ap.add_argument("--blocks", type=int, default=0, help="blocks override (0 = one lane-group batch per block)")
+    ap.add_argument("--build-dir", default=None, help="load the robot library from another build directory (tuning experiments)")
     args = ap.parse_args()
 
     import torch
@@ -91,7 +92,7 @@ def main():
     robot = RobotModel.from_fixture(ROBOT)
     n = robot.n
     N = args.batch
-    lib = load(ROBOT, device=local_rank, max_timesteps=N)  # raises if the HIP library is missing (no CPU fallback)
+    lib = load(ROBOT, device=local_rank, max_timesteps=N, build_dir=args.build_dir)  # raises if the HIP library is missing (no CPU fallback)
     if args.threads or args.blocks:
         lib.set_launch_dims(args.blocks, args.threads)
     x = make_inputs(n, N, seed=rank)  # every rank owns a different shard of the job

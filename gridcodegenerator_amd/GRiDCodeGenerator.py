@@ -64,6 +64,8 @@ class GRiDCodeGenerator:
         while lanes < need:
             lanes *= 2
         self.lanes_per_solve = lanes          # lane j of a group <-> joint j; 6 lanes also carry the articulated inertia columns
+        # tuning knob: minimum waves per SIMD the register allocator must leave room for (second __launch_bounds__ argument); 0 = compiler's choice
+        self.min_waves_per_eu = int(__import__("os").environ.get("GRID_MIN_WAVES", "0"))
         self.suggested_threads = 256
         self.max_threads = 512                # __launch_bounds__: keeps 256 VGPRs available per lane
 
@@ -104,19 +106,21 @@ class GRiDCodeGenerator:
         lds = self.lds = self.gen_lds_layout()
         G = self.lanes_per_solve
         max_groups = self.suggested_threads // G
-        count = max_groups * lds["TOTAL"]
+        count = max_groups * (lds["TOTAL"] + lds["OUT_PER_SOLVE"])
         dva_cols, df_cols = self.gen_topology_sparsity_helpers_python()
         self.gen_add_code_lines(["const int NUM_JOINTS = " + str(n) + ";",
                                  "const int NUM_VEL = " + str(n) + ";",
                                  "const int NUM_EES = " + str(sum(1 for c in self.model.children if not c)) + ";",
                                  "// lane-group decomposition: GRID_LANES_PER_SOLVE consecutive lanes of one wavefront own one solve",
                                  "const int GRID_LANES_PER_SOLVE = " + str(G) + ";",
+                                 "const int GRID_SOLVES_PER_WAVE = " + str(64 // G) + ";",
                                  "const int GRID_MAX_THREADS = " + str(self.max_threads) + "; // __launch_bounds__ of every kernel",
+                                 "#define GRID_LAUNCH_BOUNDS __launch_bounds__(" + str(self.max_threads) + (", " + str(self.min_waves_per_eu) if self.min_waves_per_eu else "") + ")",
                                  "const int SUGGESTED_THREADS = " + str(self.suggested_threads) + ";",
                                  "const int GRID_MAX_SOLVES_PER_BLOCK = SUGGESTED_THREADS/GRID_LANES_PER_SOLVE; // what the *_DYNAMIC_SHARED_MEM_COUNT constants cover",
                                  "// per-solve LDS slice (elements of T) and the offsets of its parts",
                                  "const int GRID_LDS_PER_SOLVE = " + str(lds["TOTAL"]) + ";"])
-        for k in ("IN", "X", "U", "T", "MINV", "QDD", "F", "J", "OUT"):
+        for k in ("IN", "X", "U", "T", "MINV", "QDD", "F", "J"):
             self.gen_add_code_line("const int GRID_OFF_" + k + " = " + str(lds[k]) + ";")
         for k in ("ID", "MINV", "FD", "ID_DU", "FD_DU"):
             self.gen_add_code_line("const int " + k + "_DYNAMIC_SHARED_MEM_COUNT = " + str(count) + ";")
@@ -242,7 +246,7 @@ class GRiDCodeGenerator:
         self.gen_add_includes(use_thread_group)
         self.gen_add_gpu_err()
         self.gen_add_code_line("// dynamic LDS of the block; every kernel carves one GRID_LDS_PER_SOLVE slice per lane group out of it")
-        self.gen_add_code_line("extern __shared__ unsigned char grid_smem_raw[];")
+        self.gen_add_code_line("extern __shared__ __attribute__((aligned(16))) unsigned char grid_smem_raw[];")
         self.gen_add_code_line("")
         self.gen_add_func_doc("All functions are kept in this namespace")
         self.gen_add_code_line("namespace " + self.file_namespace + " {", True)

@@ -41,7 +41,14 @@ def gen_direct_minv_inner(self, use_thread_group=False):
     self.gen_add_code_line("template <typename T>")
     self.gen_add_code_line("__device__ __forceinline__")
     self.gen_add_code_line("void direct_minv_inner(T *s_Minv, const T *s_X, T *s_U, T *s_T, const robotModel<T> *d_robotModel, const int lane) {", True)
-    self.gen_add_code_line("const int cI = lane < 5 ? lane : 5; // articulated-inertia column owned by this lane (lanes 0..5 are live)")
+    IA0 = 0 if self.cols_per_lane == 2 else self.lanes_per_solve // 2  # first of the 6 lanes that carry the articulated-inertia columns
+    shared = IA0 != 0  # F lanes and IA lanes are disjoint: one X^T product serves both
+    if IA0 == 0:
+        self.gen_add_code_line("const int cI = lane < 5 ? lane : 5; // articulated-inertia column owned by this lane (lanes 0..5 are live)")
+        self.gen_add_code_line("const bool isIA = lane < 6;")
+    else:
+        self.gen_add_code_line("const int cI = (lane < %d) ? 0 : ((lane > %d) ? 5 : (lane - %d)); // articulated-inertia column owned by this lane (lanes %d..%d are live)" % (IA0, IA0 + 5, IA0, IA0, IA0 + 5))
+        self.gen_add_code_line("const bool isIA = (lane >= %d) && (lane < %d);" % (IA0, IA0 + 6))
     self.gen_add_code_line("const T *d_I = &d_robotModel->d_XImats[" + str(18 * n) + " + 6*cI];")
     self.gen_add_code_line("T Mcol[" + str(n) + "];")
     self.gen_add_code_line("//")
@@ -55,7 +62,7 @@ def gen_direct_minv_inner(self, use_thread_group=False):
 
     def post_b(i):
         s, p = m.S_index[i], m.parent[i]
-        self.gen_add_code_line("if (lane == %d) {" % s, True)
+        self.gen_add_code_line("if (lane == %d) {" % (IA0 + s), True)
         self.gen_add_code_line("#pragma unroll")
         self.gen_add_code_line("for (int r = 0; r < 6; r++) { s_U[%d + r] = IA_%d[r]; }" % (8 * i, i))
         self.gen_add_end_control_flow()
@@ -64,7 +71,7 @@ def gen_direct_minv_inner(self, use_thread_group=False):
         self.gen_add_code_line("T U[6];")
         self.gen_add_code_line("#pragma unroll")
         self.gen_add_code_line("for (int r = 0; r < 6; r++) { U[r] = s_U[%d + r]; }" % (8 * i))
-        self.gen_add_code_line("const T Dinv = static_cast<T>(1)/U[%d];" % s)
+        self.gen_add_code_line("const T Dinv = grid_rcp(U[%d]);" % s)
         self.gen_add_code_line("if (lane == 0) { s_U[%d] = Dinv; }" % (8 * i + 6))
         self.gen_add_code_line("const T m = ((lane == %d) ? Dinv : static_cast<T>(0)) - Dinv*F_%d[%d];" % (i, i, s))
         self.gen_add_code_line("Mcol[%d] = m; grid_pin(Mcol[%d]);" % (i, i))
@@ -72,16 +79,25 @@ def gen_direct_minv_inner(self, use_thread_group=False):
             self.gen_add_code_line("T X[18]; grid_load_X(X, &s_X[GRID_X_STRIDE*%d]);" % i)
             self.gen_add_code_line("#pragma unroll")
             self.gen_add_code_line("for (int r = 0; r < 6; r++) { F_%d[r] += U[r]*m; }" % i)
-            self.gen_add_code_line("grid_xtmul_peq(F_%d, X, F_%d); grid_pin6(F_%d);" % (p, i, p))
             self.gen_add_code_line("// IA_parent += X^T (IA - U Dinv U^T) X, one column per lane, transposed through LDS")
             self.gen_add_code_line("T Ia[6], Tc[6], Tr[6];")
             self.gen_add_code_line("const T w = Dinv*IA_%d[%d];" % (i, s))
             self.gen_add_code_line("#pragma unroll")
             self.gen_add_code_line("for (int r = 0; r < 6; r++) { Ia[r] = IA_%d[r] - U[r]*w; }" % i)
-            self.gen_add_code_line("grid_xtmul(Tc, X, Ia);")
-            self.gen_add_code_line("if (lane < 6) {", True)
+            if not shared:
+                self.gen_add_code_line("grid_xtmul_peq(F_%d, X, F_%d); grid_pin6(F_%d);" % (p, i, p))
+                self.gen_add_code_line("grid_xtmul(Tc, X, Ia);")
+            else:
+                self.gen_add_code_line("// the F lanes and the IA lanes are disjoint: one X^T product serves both")
+                self.gen_add_code_line("#pragma unroll")
+                self.gen_add_code_line("for (int r = 0; r < 6; r++) { Ia[r] = isIA ? Ia[r] : F_%d[r]; }" % i)
+                self.gen_add_code_line("grid_xtmul(Tc, X, Ia);")
+                self.gen_add_code_line("#pragma unroll")
+                self.gen_add_code_line("for (int r = 0; r < 6; r++) { F_%d[r] += isIA ? static_cast<T>(0) : Tc[r]; }" % p)
+                self.gen_add_code_line("grid_pin6(F_%d);" % p)
+            self.gen_add_code_line("if (isIA) {", True)
             self.gen_add_code_line("#pragma unroll")
-            self.gen_add_code_line("for (int r = 0; r < 6; r++) { s_T[8*r + lane] = Tc[r]; }")
+            self.gen_add_code_line("for (int r = 0; r < 6; r++) { s_T[8*r + cI] = Tc[r]; }")
             self.gen_add_end_control_flow()
             self.gen_add_sync(use_thread_group)
             self.gen_add_code_line("#pragma unroll")
@@ -139,13 +155,13 @@ def gen_direct_minv_kernel(self, use_thread_group=False, single_call_timing=Fals
         func_def = func_def.replace("kernel(", "kernel_single_timing(")
     self.gen_add_func_doc("Compute the inverse of the mass matrix", ["Outputs a SYMMETRIC_UPPER triangular matrix for Minv (as the reference does)"], func_params, None)
     self.gen_add_code_line("template <typename T>")
-    self.gen_add_code_line("__global__ __launch_bounds__(GRID_MAX_THREADS)")
+    self.gen_add_code_line("__global__ GRID_LAUNCH_BOUNDS")
     self.gen_add_code_line(func_def, True)
     self.gen_kernel_prologue("GRID_LDS_PER_SOLVE")
     self.gen_add_code_lines(["T *s_q = &s_mem[GRID_OFF_IN];",
-                             "T *s_X = &s_mem[GRID_OFF_X]; T *s_U = &s_mem[GRID_OFF_U]; T *s_T = &s_mem[GRID_OFF_T]; T *s_Minv = &s_mem[GRID_OFF_MINV]; T *s_out = &s_mem[GRID_OFF_OUT];"])
+                             "T *s_X = &s_mem[GRID_OFF_X]; T *s_U = &s_mem[GRID_OFF_U]; T *s_T = &s_mem[GRID_OFF_T]; T *s_Minv = &s_mem[GRID_OFF_MINV]; T *s_out = &s_out_all[grp*%d];" % (n * n)])
     if single_call_timing:
-        self.gen_add_code_line("const int k = 0; const int kc = 0; const bool valid = (blockIdx.x + blockIdx.y == 0) && (grp == 0); const int lane = lane_id;")
+        self.gen_add_code_line("const int k = 0; const int kc = 0; const bool valid = (blockIdx.x + blockIdx.y == 0) && (grp == 0); const int lane = lane_id; const int NUM_TIMESTEPS_OUT = 1;")
         self.gen_add_code_line("if (!valid) {return;}")
     else:
         self.gen_add_parallel_loop("k", "NUM_TIMESTEPS", use_thread_group, block_level=True)

@@ -112,17 +112,17 @@ def gen_forward_dynamics_gradient_kernel(self, use_thread_group=False, use_qdd_M
     self.gen_add_func_doc("Computes the gradient of forward dynamics",
                           ["output layout d_df_du[k*2n^2 + col*n + row], col in [0,2n) = [d qdd/dq | d qdd/dqd] (column-major n x 2n)"], func_params, None)
     self.gen_add_code_line("template <typename T>")
-    self.gen_add_code_line("__global__ __launch_bounds__(GRID_MAX_THREADS)")
+    self.gen_add_code_line("__global__ GRID_LAUNCH_BOUNDS")
     self.gen_add_code_line(func_def, True)
     self.gen_kernel_prologue("GRID_LDS_PER_SOLVE")
     if use_qdd_Minv_input:
         self.gen_add_code_line("T *s_q_qd = &s_mem[GRID_OFF_IN]; T *s_q = s_q_qd; T *s_qd = &s_q_qd[%d]; T *s_qdd = &s_mem[GRID_OFF_QDD];" % n)
     else:
         self.gen_add_code_line("T *s_q_qd_u = &s_mem[GRID_OFF_IN]; T *s_q = s_q_qd_u; T *s_qd = &s_q_qd_u[%d]; T *s_u = &s_q_qd_u[%d]; T *s_qdd = &s_mem[GRID_OFF_QDD];" % (n, 2 * n))
-    self.gen_add_code_line("T *s_X = &s_mem[GRID_OFF_X]; T *s_U = &s_mem[GRID_OFF_U]; T *s_T = &s_mem[GRID_OFF_T]; T *s_Minv = &s_mem[GRID_OFF_MINV]; T *s_F = &s_mem[GRID_OFF_F]; T *s_J = &s_mem[GRID_OFF_J]; T *s_df_du = &s_mem[GRID_OFF_OUT];")
+    self.gen_add_code_line("T *s_X = &s_mem[GRID_OFF_X]; T *s_U = &s_mem[GRID_OFF_U]; T *s_T = &s_mem[GRID_OFF_T]; T *s_Minv = &s_mem[GRID_OFF_MINV]; T *s_F = &s_mem[GRID_OFF_F]; T *s_J = &s_mem[GRID_OFF_J]; T *s_df_du = &s_out_all[grp*%d];" % (2 * n * n))
     self.gen_add_code_line("(void)s_U; (void)s_T;")
     if single_call_timing:
-        self.gen_add_code_line("const int k = 0; const int kc = 0; const bool valid = (blockIdx.x + blockIdx.y == 0) && (grp == 0); const int lane = lane_id;")
+        self.gen_add_code_line("const int k = 0; const int kc = 0; const bool valid = (blockIdx.x + blockIdx.y == 0) && (grp == 0); const int lane = lane_id; const int NUM_TIMESTEPS_OUT = 1;")
         self.gen_add_code_line("if (!valid) {return;}")
     else:
         self.gen_add_parallel_loop("k", "NUM_TIMESTEPS", use_thread_group, block_level=True)

@@ -61,6 +61,7 @@ def gen_add_parallel_loop(self, var_name, max_val, use_thread_group=False, block
                                "; " + var_name + "0 += gridDim.x*gridDim.y*gpb){", True)
         self.gen_add_code_line("const int " + var_name + " = " + var_name + "0 + grp; const bool valid = " + var_name + " < " + max_val +
                                "; const int " + var_name + "c = valid ? " + var_name + " : " + max_val + " - 1;")
+        self.gen_add_code_line("const int NUM_TIMESTEPS_OUT = " + max_val + ";")
         self.gen_add_code_line("const int lane = grid_loop_variant(lane_id); // keeps lane-dependent values from being hoisted out of the batch loop (and spilled)")
     else:
         self.gen_add_code_line("for(int " + var_name + " = lane; " + var_name + " < " + max_val + "; " + var_name +
@@ -102,6 +103,8 @@ def gen_kernel_prologue(self, lds_per_solve_const):
         "int gpb = (blockDim.x*blockDim.y) / GRID_LANES_PER_SOLVE; if (gpb > GRID_MAX_SOLVES_PER_BLOCK) {gpb = GRID_MAX_SOLVES_PER_BLOCK;}",
         "if (grp >= gpb) {return;}",
         "T *s_mem = reinterpret_cast<T *>(grid_smem_raw) + grp*" + lds_per_solve_const + ";",
+        "// output staging lives behind all slices so that the records of a wave's lane groups are contiguous",
+        "T *s_out_all = reinterpret_cast<T *>(grid_smem_raw) + GRID_MAX_SOLVES_PER_BLOCK*" + lds_per_solve_const + ";",
     ])
 
 
@@ -132,15 +135,22 @@ def gen_kernel_load_inputs(self, name, stride, amount, use_thread_group=False, n
 
 
 def gen_kernel_save_result(self, store_to_name, stride, amount, use_thread_group=False, load_from_name=None):
-    """this solve's LDS slice -> global, lanes strided over the contiguous output record."""
+    """LDS staging -> global.  The lane groups of one wavefront own CONSECUTIVE solves and their staging records are
+    contiguous in LDS (s_out_wave), so the wave's output is one contiguous span of global memory: every lane moves 16 bytes
+    per trip (ds_read_b128 + global_store_dwordx4), with a dword tail.  `stride` must equal `amount` (contiguous records)."""
+    assert str(stride) == str(amount)
     if load_from_name is None:
         load_from_name = "s_" + store_to_name
     self.gen_add_sync(use_thread_group)
-    self.gen_add_code_line("// save down to global")
-    self.gen_add_code_line("if (valid) {", True)
-    self.gen_add_code_line("T *d_" + store_to_name + "_k = &d_" + store_to_name + "[k*" + str(stride) + "];")
-    self.gen_add_parallel_loop("ind", str(amount), use_thread_group)
-    self.gen_add_code_line("d_" + store_to_name + "_k[ind] = " + load_from_name + "[ind];")
-    self.gen_add_end_control_flow()
+    self.gen_add_code_line("// save down to global: wave-cooperative, coalesced")
+    self.gen_add_code_line("{", True)
+    self.gen_add_code_lines(["const int gw0 = grp & ~(GRID_SOLVES_PER_WAVE-1); // first lane group of this wave",
+                             "int nv = NUM_TIMESTEPS_OUT - (k - grp + gw0); { const int ng = gpb - gw0; nv = nv < ng ? nv : ng; nv = nv < GRID_SOLVES_PER_WAVE ? nv : GRID_SOLVES_PER_WAVE; }",
+                             "const int total = nv*" + str(amount) + "; // elements this wave writes",
+                             "const T *src = " + load_from_name + " - (grp - gw0)*" + str(amount) + ";",
+                             "T *dst = &d_" + store_to_name + "[(k - grp + gw0)*" + str(amount) + "];",
+                             "const int wl = tid & 63;",
+                             "for (int e = 4*wl; e + 3 < total; e += 256) { T tmp[4]; __builtin_memcpy(tmp, __builtin_assume_aligned(src + e, 4*sizeof(T) < 16 ? 4*sizeof(T) : 16), 4*sizeof(T)); __builtin_memcpy(dst + e, tmp, 4*sizeof(T)); }",
+                             "{ const int e = (total & ~3) + wl; if (wl < 3 && e < total) { dst[e] = src[e]; } }"])
     self.gen_add_end_control_flow()
     self.gen_add_sync(use_thread_group)

@@ -38,6 +38,10 @@ __device__ __forceinline__ void grid_pin6(T (&v)[6]) {
     for (int r = 0; r < 6; r++) { asm volatile("" : "+v"(v[r])); }
 }
 
+// reciprocal: one v_rcp_f32 (1 ulp) instead of the ~10-instruction IEEE division sequence
+__device__ __forceinline__ float grid_rcp(const float x) { return __frcp_rn(x); }
+__device__ __forceinline__ double grid_rcp(const double x) { return 1.0/x; }
+
 // X is stored compactly per joint: X[0..8] = E (row-major 3x3, top-left == bottom-right block),
 // X[9..17] = B (bottom-left block); the top-right block is identically zero.
 #define GRID_X_STRIDE 20  // floats per joint in LDS (18 used; keeps every joint 16-byte aligned)

@@ -32,13 +32,13 @@ def gen_lds_layout(self):
                        ("MINV", _pad4(n * n)),        # dense symmetric M^-1 (col*n+row == row*n+col)
                        ("QDD", _pad4(n)),
                        ("F", 8 * n),                  # wave-uniform link forces parked between the two sweeps of the gradient walk
-                       ("J", 8 * n),                  # velocity Jacobian columns of the current link (published by the d/dqd lanes)
-                       ("OUT", _pad4(2 * n * n))):    # output staging for coalesced stores
+                       ("J", 8 * n)):                 # velocity Jacobian columns of the current link (published by the d/dqd lanes)
         off[name] = cur
         cur += size
     if (cur // 4) % 2 == 0:
         cur += 4
     off["TOTAL"] = cur
+    off["OUT_PER_SOLVE"] = _pad4(2 * n * n)  # output staging, kept behind all slices (contiguous across the lane groups of a wave)
     return off
 
 

@@ -30,27 +30,27 @@ def library_path(robot_name, build_dir=None):
     return os.path.join(build_dir or BUILD_DIR, robot_name, "libgrid_%s.so" % robot_name)
 
 
-def generate_header(robot, out_dir, namespace="grid"):
+def generate_header(robot, out_dir, namespace="grid", cols_per_lane=None):
     """Runs GRiDCodeGenerator(robot).gen_all_code() with out_dir as the working directory (the generator writes
     <namespace>.cuh into the cwd, like the reference does)."""
     os.makedirs(out_dir, exist_ok=True)
     cwd = os.getcwd()
     os.chdir(out_dir)
     try:
-        GRiDCodeGenerator(robot, FILE_NAMESPACE=namespace).gen_all_code()
+        GRiDCodeGenerator(robot, FILE_NAMESPACE=namespace, COLS_PER_LANE=cols_per_lane).gen_all_code()
     finally:
         os.chdir(cwd)
     return os.path.join(out_dir, namespace + ".cuh")
 
 
-def build_library(robot, build_dir=None, force=False, extra_flags=(), verbose=False):
+def build_library(robot, build_dir=None, force=False, extra_flags=(), verbose=False, cols_per_lane=None):
     """robot: a fixture name, a RobotModel, or any URDFParser-style robot object.  Returns the .so path."""
     if isinstance(robot, str):
         robot = RobotModel.from_fixture(robot)
     name = robot.name
     out_dir = os.path.join(build_dir or BUILD_DIR, name)
     so = library_path(name, build_dir)
-    header = generate_header(robot, out_dir)
+    header = generate_header(robot, out_dir, cols_per_lane=cols_per_lane)
     stamp = so + ".stamp"
     srcs_mtime = max(os.path.getmtime(p) for p in (header, CAPI_SRC, os.path.join(INCLUDE_DIR, "grid_capi.h")))
     sig = open(header).read() + open(CAPI_SRC).read() + " ".join(HIPCC_FLAGS + list(extra_flags))

@@ -53,7 +53,7 @@ inline hipError_t hipStreamCreateWithPriority(hipStream_t *s, unsigned, int) { *
 inline hipError_t hipStreamDestroy(hipStream_t) { return hipSuccess; }
 
 // dynamic LDS of the (single) running block
-alignas(16) unsigned char grid_smem_raw[160 * 1024];  // (one definition: the emulation harness is a single translation unit)
+__attribute__((aligned(16))) unsigned char grid_smem_raw[160 * 1024];  // (one definition: the emulation harness is a single translation unit)
 
 namespace hipemu {
 inline std::barrier<> *g_barrier = nullptr;
@@ -82,6 +82,7 @@ void launch(dim3 grid, dim3 block, size_t smem_bytes, F &&body) {
 }
 }  // namespace hipemu
 
+inline float __frcp_rn(float x) { return 1.0f / x; }
 #define __builtin_amdgcn_fence(order, scope) ((void)0)
 #define __builtin_amdgcn_wave_barrier() hipemu::wave_barrier()
 #define hipLaunchKernelGGL(kernel, grid, block, smem, stream, ...) hipemu::launch((grid), (block), (smem), [&]() { kernel(__VA_ARGS__); })

@@ -12,16 +12,16 @@ EMU_INC = os.path.join(HERE, "emu")
 _CACHE = {}
 
 
-def emu_library(robot, max_timesteps=64):
+def emu_library(robot, max_timesteps=64, cols_per_lane=None):
     if isinstance(robot, str):
         robot = RobotModel.from_fixture(robot)
-    key = robot.name
+    key = robot.name + ("" if cols_per_lane is None else "_c%d" % cols_per_lane)
     if key not in _CACHE:
         out_dir = os.path.join(tempfile.gettempdir(), "grid_emu_build", key)
-        generate_header(robot, out_dir)
+        generate_header(robot, out_dir, cols_per_lane=cols_per_lane)
         so = os.path.join(out_dir, "libgrid_emu_%s.so" % key)
         cmd = ["g++", "-std=c++20", "-O1", "-g0", "-x", "c++", "-shared", "-fPIC", "-pthread", "-I" + EMU_INC, "-I" + out_dir, "-I" + INCLUDE_DIR,
-               '-DGRID_ROBOT_NAME="%s"' % key, "-Wno-unused-value", CAPI_SRC, "-o", so]
+               '-DGRID_ROBOT_NAME="%s"' % robot.name, "-Wno-unused-value", CAPI_SRC, "-o", so]
         subprocess.check_call(cmd)
         _CACHE[key] = so
     return GridLibrary(_CACHE[key], device=0, max_timesteps=max_timesteps)

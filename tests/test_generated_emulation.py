@@ -40,6 +40,27 @@ def test_emulated_fd_grad_matches_goldens(name, libs, golden):
     assert per_solve_err(out, ref) <= TOL
 
 
+@pytest.mark.parametrize("name", ["iiwa14", "hyq", "mixed5"])
+def test_emulated_one_column_per_lane_variant(name, golden):
+    """COLS_PER_LANE=1: d/dq columns on the first half of the lane group, d/dqd columns on the second half, the
+    articulated-inertia columns ride on lanes of the second half (all kernels share the lane mapping)."""
+    g = golden(name)
+    lib = emu_library(name, max_timesteps=64, cols_per_lane=1)
+    n = lib.n
+    assert lib.lanes_per_solve >= 2 * n
+    N = 6
+    x = np.ascontiguousarray(np.hstack([g["q"], g["qd"], g["u"]]).astype(np.float32)[:N])
+    lib.set_launch_dims(0, 64)
+    out = lib.forward_dynamics_gradient_host(x)
+    assert per_solve_err(out, np.stack([g["df_du"][k].T.reshape(-1) for k in range(N)])) <= TOL
+    Minv = np.zeros((N, n * n), np.float32)
+    lib.direct_minv_device(x, N, Minv)
+    assert per_solve_err(Minv, np.stack([g["Minv_upper"][k].T.reshape(-1) for k in range(N)])) <= TOL
+    dc = np.zeros((N, 2 * n * n), np.float32)
+    lib.inverse_dynamics_gradient_device(x, np.ascontiguousarray(g["qdd"].astype(np.float32)[:N]), N, dc)
+    assert per_solve_err(dc, np.stack([g["dc_du"][k].T.reshape(-1) for k in range(N)])) <= TOL
+
+
 @pytest.mark.parametrize("blocks,threads", [(1, 64), (2, 24), (1, 8), (3, 40)])
 def test_emulated_ragged_launch_dims_and_grid_stride(blocks, threads, libs, golden):
     g = golden("iiwa14")
