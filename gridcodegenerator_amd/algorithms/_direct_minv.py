@@ -62,6 +62,7 @@ def gen_direct_minv_inner(self, use_thread_group=False):
 
     def post_b(i):
         s, p = m.S_index[i], m.parent[i]
+        tbuf = (m.depth[i] & 1) * 40  # the transpose scratch is double buffered by depth parity
         self.gen_add_code_line("if (lane == %d) {" % (IA0 + s), True)
         self.gen_add_code_line("#pragma unroll")
         self.gen_add_code_line("for (int r = 0; r < 6; r++) { s_U[%d + r] = IA_%d[r]; }" % (8 * i, i))
@@ -97,13 +98,12 @@ def gen_direct_minv_inner(self, use_thread_group=False):
                 self.gen_add_code_line("grid_pin6(F_%d);" % p)
             self.gen_add_code_line("if (isIA) {", True)
             self.gen_add_code_line("#pragma unroll")
-            self.gen_add_code_line("for (int r = 0; r < 6; r++) { s_T[8*r + cI] = Tc[r]; }")
+            self.gen_add_code_line("for (int r = 0; r < 6; r++) { s_T[%d + 6*r + cI] = Tc[r]; }" % tbuf)
             self.gen_add_end_control_flow()
             self.gen_add_sync(use_thread_group)
             self.gen_add_code_line("#pragma unroll")
-            self.gen_add_code_line("for (int r = 0; r < 6; r++) { Tr[r] = s_T[8*cI + r]; }")
+            self.gen_add_code_line("for (int r = 0; r < 6; r++) { Tr[r] = s_T[%d + 6*cI + r]; }" % tbuf)
             self.gen_add_code_line("grid_xtmul_peq(IA_%d, X, Tr); grid_pin6(IA_%d);" % (p, p))
-            self.gen_add_sync(use_thread_group)
         self.gen_add_end_control_flow()
 
     self.gen_tree_traversal(pre_b, post_b)
@@ -178,7 +178,10 @@ def gen_direct_minv_kernel(self, use_thread_group=False, single_call_timing=Fals
     self.gen_add_code_line("const int row = ind %% %d; const int col = ind / %d;" % (n, n))
     self.gen_add_code_line("s_out[ind] = (row <= col) ? s_Minv[ind] : static_cast<T>(0);")
     self.gen_add_end_control_flow()
-    self.gen_kernel_save_result("Minv", n * n, n * n, use_thread_group, "s_out")
+    if single_call_timing:
+        self.gen_kernel_save_result_single_timing("Minv", n * n, use_thread_group, "s_out")
+    else:
+        self.gen_kernel_save_result("Minv", n * n, n * n, use_thread_group, "s_out")
     if not single_call_timing:
         self.gen_add_end_control_flow()
     self.gen_add_end_function()

@@ -85,7 +85,10 @@ def gen_forward_dynamics_kernel(self, use_thread_group=False, single_call_timing
     self.gen_forward_dynamics_inner_function_call(use_thread_group)
     if single_call_timing:
         self.gen_add_end_control_flow()
-    self.gen_kernel_save_result("qdd", n, n, use_thread_group)
+    if single_call_timing:
+        self.gen_kernel_save_result_single_timing("qdd", n, use_thread_group)
+    else:
+        self.gen_kernel_save_result("qdd", n, n, use_thread_group)
     if not single_call_timing:
         self.gen_add_end_control_flow()
     self.gen_add_end_function()

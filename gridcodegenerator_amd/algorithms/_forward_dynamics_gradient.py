@@ -138,7 +138,10 @@ def gen_forward_dynamics_gradient_kernel(self, use_thread_group=False, use_qdd_M
     self.gen_forward_dynamics_gradient_inner_python(use_thread_group, use_qdd_Minv_input)
     if single_call_timing:
         self.gen_add_end_control_flow()
-    self.gen_kernel_save_result("df_du", 2 * n * n, 2 * n * n, use_thread_group)
+    if single_call_timing:
+        self.gen_kernel_save_result_single_timing("df_du", 2 * n * n, use_thread_group)
+    else:
+        self.gen_kernel_save_result("df_du", 2 * n * n, 2 * n * n, use_thread_group)
     if not single_call_timing:
         self.gen_add_end_control_flow()
     self.gen_add_end_function()

@@ -128,7 +128,10 @@ def gen_inverse_dynamics_kernel(self, use_thread_group=False, use_qdd_input=Fals
     self.gen_add_end_control_flow()
     if single_call_timing:
         self.gen_add_end_control_flow()
-    self.gen_kernel_save_result("c", n, n, use_thread_group)
+    if single_call_timing:
+        self.gen_kernel_save_result_single_timing("c", n, use_thread_group)
+    else:
+        self.gen_kernel_save_result("c", n, n, use_thread_group)
     if not single_call_timing:
         self.gen_add_end_control_flow()
     self.gen_add_end_function()

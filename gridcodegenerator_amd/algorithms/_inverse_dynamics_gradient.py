@@ -80,6 +80,7 @@ def gen_inverse_dynamics_gradient_inner(self, use_thread_group=False):
     def pre(k):
         s, p = m.S_index[k], m.parent[k]
         K, P = str(k), str(p)
+        jbuf = (m.depth[k] & 1) * ((6 * n + 3) // 4 * 4)  # s_J is double buffered by depth parity: no hand-off sync is needed after the dots
         if C == 2:
             self.gen_add_code_line("const T self_%s = (jcol == %s) ? %s : %s;" % (K, K, ONE, ZERO))
             selq, seld = "self_" + K, "self_" + K
@@ -111,7 +112,7 @@ def gen_inverse_dynamics_gradient_inner(self, use_thread_group=False):
         self.gen_add_code_line("{ T f[6]; grid_imul_%s(Iv, v_%s); grid_imul_%s(f, a_%s); grid_fxv_peq(f, v_%s, Iv);" % (K, K, K, K, K))
         self.gen_add_code_line("  if (lane == 0) {")
         self.gen_add_code_line("      #pragma unroll")
-        self.gen_add_code_line("      for (int r = 0; r < 6; r++) { s_F[%d + r] = f[r]; }" % (8 * k))
+        self.gen_add_code_line("      for (int r = 0; r < 6; r++) { s_F[%d + r] = f[r]; }" % (6 * k))
         self.gen_add_code_line("  } }")
         self.gen_add_code_line("// this lane's column(s): dv, da (forward recursions with the self terms of column == joint)")
         if C == 2:
@@ -141,11 +142,11 @@ def gen_inverse_dynamics_gradient_inner(self, use_thread_group=False):
         if C == 2:
             self.gen_add_code_line("if (lane < %d) {" % n, True)
             self.gen_add_code_line("#pragma unroll")
-            self.gen_add_code_line("for (int r = 0; r < 6; r++) { s_J[8*lane + r] = dvd_%s[r]; }" % K)
+            self.gen_add_code_line("for (int r = 0; r < 6; r++) { s_J[%d + 6*lane + r] = dvd_%s[r]; }" % (jbuf, K))
         else:
             self.gen_add_code_line("if (is_qd && jcol < %d) {" % n, True)
             self.gen_add_code_line("#pragma unroll")
-            self.gen_add_code_line("for (int r = 0; r < 6; r++) { s_J[8*jcol + r] = dvu_%s[r]; }" % K)
+            self.gen_add_code_line("for (int r = 0; r < 6; r++) { s_J[%d + 6*jcol + r] = dvu_%s[r]; }" % (jbuf, K))
         self.gen_add_end_control_flow()
         self.gen_add_code_line("// local df = I da + fx(dv) (I v) + fx(v) (I dv), consumed at once: dc[a] += J_{k,a} . df for a in ancestors(k) + {k}")
         for c in cols:
@@ -154,9 +155,8 @@ def gen_inverse_dynamics_gradient_inner(self, use_thread_group=False):
         for a in m.ancestors[k] + [k]:
             self.gen_add_code_line("{ T J[6];")
             self.gen_add_code_line("  #pragma unroll")
-            self.gen_add_code_line("  for (int r = 0; r < 6; r++) { J[r] = s_J[%d + r]; }" % (8 * a))
+            self.gen_add_code_line("  for (int r = 0; r < 6; r++) { J[r] = s_J[%d + r]; }" % (jbuf + 6 * a))
             self.gen_add_code_line("  " + " ".join("%s[%d] += grid_dot6(J, df%s); grid_pin(%s[%d]);" % (dcs[c], a, c, dcs[c], a) for c in cols) + " }")
-        self.gen_add_sync(use_thread_group)  # s_J is rewritten by the next link
         self.gen_add_end_control_flow()
 
     def post(k):
@@ -170,19 +170,21 @@ def gen_inverse_dynamics_gradient_inner(self, use_thread_group=False):
         self.gen_add_code_line("%s[%s] -= w_%s[%d];" % (dcs[qcol], K, K, s))
         if damp != 0.0:
             self.gen_add_code_line("%s[%s] += %s*static_cast<T>(%s);" % (dcs["d" if C == 2 else "u"], K, seld, repr(float(damp))))
+        if p == -1 and k != m.roots[-1]:
+            self.gen_add_sync(use_thread_group)  # the next root's subtree reuses the depth-0 J buffer
         if p != -1:
             self.gen_add_sync(use_thread_group)
             self.gen_add_code_line("{", True)
             self.gen_add_code_line("T X[18]; grid_load_X(X, &s_X[GRID_X_STRIDE*" + K + "]);")
             self.gen_add_code_line("T f[6], fp[6];")
             self.gen_add_code_line("#pragma unroll")
-            self.gen_add_code_line("for (int r = 0; r < 6; r++) { f[r] = s_F[%d + r]; fp[r] = s_F[%d + r]; }" % (8 * k, 8 * p))
+            self.gen_add_code_line("for (int r = 0; r < 6; r++) { f[r] = s_F[%d + r]; fp[r] = s_F[%d + r]; }" % (6 * k, 6 * p))
             self.gen_add_code_line("// column == joint injects mxS(S, f_subtree); everything is carried to the parent frame")
             self.gen_add_code_line("grid_mxS_peq<T,%d>(w_%s, f, %s);" % (s, K, selq))
             self.gen_add_code_line("grid_xtmul_peq(fp, X, f); grid_xtmul_peq(w_%s, X, w_%s); grid_pin6(w_%s);" % (P, K, P))
             self.gen_add_code_line("if (lane == 0) {", True)
             self.gen_add_code_line("#pragma unroll")
-            self.gen_add_code_line("for (int r = 0; r < 6; r++) { s_F[%d + r] = fp[r]; }" % (8 * p))
+            self.gen_add_code_line("for (int r = 0; r < 6; r++) { s_F[%d + r] = fp[r]; }" % (6 * p))
             self.gen_add_end_control_flow()
             self.gen_add_end_control_flow()
 
@@ -248,7 +250,10 @@ def gen_inverse_dynamics_gradient_kernel(self, use_thread_group=False, use_qdd_i
     self.gen_dc_du_to_lds("s_dc_du")
     if single_call_timing:
         self.gen_add_end_control_flow()
-    self.gen_kernel_save_result("dc_du", 2 * n * n, 2 * n * n, use_thread_group)
+    if single_call_timing:
+        self.gen_kernel_save_result_single_timing("dc_du", 2 * n * n, use_thread_group)
+    else:
+        self.gen_kernel_save_result("dc_du", 2 * n * n, 2 * n * n, use_thread_group)
     if not single_call_timing:
         self.gen_add_end_control_flow()
     self.gen_add_end_function()

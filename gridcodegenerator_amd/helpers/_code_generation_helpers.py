@@ -134,6 +134,17 @@ def gen_kernel_load_inputs(self, name, stride, amount, use_thread_group=False, n
     self.gen_add_sync(use_thread_group)
 
 
+def gen_kernel_save_result_single_timing(self, store_to_name, amount, use_thread_group=False, load_from_name=None):
+    """Timing kernels run ONE solve on ONE lane group: plain lane-strided store of its record."""
+    if load_from_name is None:
+        load_from_name = "s_" + store_to_name
+    self.gen_add_sync(use_thread_group)
+    self.gen_add_code_line("// save down to global")
+    self.gen_add_parallel_loop("ind", str(amount), use_thread_group)
+    self.gen_add_code_line("d_" + store_to_name + "[ind] = " + load_from_name + "[ind];")
+    self.gen_add_end_control_flow()
+
+
 def gen_kernel_save_result(self, store_to_name, stride, amount, use_thread_group=False, load_from_name=None):
     """LDS staging -> global.  The lane groups of one wavefront own CONSECUTIVE solves and their staging records are
     contiguous in LDS (s_out_wave), so the wave's output is one contiguous span of global memory: every lane moves 16 bytes

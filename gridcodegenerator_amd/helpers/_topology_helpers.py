@@ -28,11 +28,11 @@ def gen_lds_layout(self):
     for name, size in (("IN", _pad4(4 * n)),          # q | qd | u  (| spare: qdd input for the qdd/Minv overloads)
                        ("X", 20 * n),                 # compact X(q): 18 of every 20
                        ("U", 8 * n),                  # U_i (6), 1/D_i, pad
-                       ("T", 48),                     # 6x6 transpose scratch (row stride 8)
+                       ("T", 80),                     # 6x6 transpose scratch (row stride 6, 40 per buffer), double buffered by tree-depth parity
                        ("MINV", _pad4(n * n)),        # dense symmetric M^-1 (col*n+row == row*n+col)
                        ("QDD", _pad4(n)),
-                       ("F", 8 * n),                  # wave-uniform link forces parked between the two sweeps of the gradient walk
-                       ("J", 8 * n)):                 # velocity Jacobian columns of the current link (published by the d/dqd lanes)
+                       ("F", _pad4(6 * n)),                # wave-uniform link forces parked between the two sweeps of the gradient walk
+                       ("J", 2 * _pad4(6 * n))):      # velocity Jacobian columns of the current link (published by the d/dqd lanes), double buffered
         off[name] = cur
         cur += size
     if (cur // 4) % 2 == 0:
