@@ -50,13 +50,51 @@ def cpu_baseline(robot, x, budget_s=12.0):
     t0 = time.perf_counter()
     _, cores = orc.fd_grad_batch(sample, nthreads=0)
     dt = time.perf_counter() - t0
-    reps = max(1, min(200, int(budget_s / max(dt, 1e-6))))
+    reps = max(1, min(100000, int(budget_s / max(dt, 1e-6))))
     t0 = time.perf_counter()
     for _ in range(reps):
         orc.fd_grad_batch(sample, nthreads=0)
     dt = time.perf_counter() - t0
     return {"value": reps * sample.shape[0] / dt, "unit": "solves/s", "cores": int(cores), "kind": "port",
             "sample": "%d x %d iiwa14 solves of the bench batch, fp32 C oracle (oracle/rbd_oracle.c, -O3 -march=native, OpenMP static), %.1f s" % (reps, sample.shape[0], dt)}
+
+
+def shard_seed(rank):
+    """Every rank owns its own batch: rank r generates shard r of the job's synthetic input (no data-path collective)."""
+    return rank
+
+
+def reduce_max(elapsed, dist, device):
+    import torch
+
+    t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def harness_selftest(args):
+    """Multi-rank plumbing only (gloo, CPU): no kernels, no metric."""
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    dist.init_process_group(backend="gloo")
+    x = make_inputs(7, 64, seed=shard_seed(rank))
+    checksum = torch.tensor([float(np.abs(x).sum())], dtype=torch.float64)
+    sums = [torch.zeros(1, dtype=torch.float64) for _ in range(world)]
+    dist.all_gather(sums, checksum)
+    dist.barrier()
+    t0 = time.perf_counter()
+    time.sleep(0.01 * (rank + 1))  # rank-dependent "work": the reported time must be the slowest rank's
+    elapsed = reduce_max(time.perf_counter() - t0, dist, torch.device("cpu"))
+    dist.barrier()
+    if rank == 0:
+        print(json.dumps({"selftest": "bench harness", "n_gpus": world, "max_elapsed_s": elapsed,
+                          "distinct_shards": len(set(round(float(s.item()), 6) for s in sums)) == world,
+                          "solves_counted": world * args.batch * args.steps}))
+    dist.destroy_process_group()
 
 
 def main():
@@ -69,7 +107,12 @@ def main():
     ap.add_argument("--threads", type=int, default=0, help="threads per block override (0 = library default)")
     ap.add_argument("--blocks", type=int, default=0, help="blocks override (0 = one lane-group batch per block)")
     ap.add_argument("--build-dir", default=None, help="load the robot library from another build directory (tuning experiments)")
+    ap.add_argument("--harness-selftest", action="store_true",
+                    help="CPU-only check of the multi-rank harness (gloo rendezvous, sharding, barrier, MAX-reduce, single JSON line); "
+                         "runs NO dynamics and reports NO metric - used by tests/test_bench_distributed.py")
     args = ap.parse_args()
+    if args.harness_selftest:
+        return harness_selftest(args)
 
     import torch
 
@@ -95,7 +138,7 @@ def main():
     lib = load(ROBOT, device=local_rank, max_timesteps=N, build_dir=args.build_dir)  # raises if the HIP library is missing (no CPU fallback)
     if args.threads or args.blocks:
         lib.set_launch_dims(args.blocks, args.threads)
-    x = make_inputs(n, N, seed=rank)  # every rank owns a different shard of the job
+    x = make_inputs(n, N, seed=shard_seed(rank))  # every rank owns a different shard of the job
     d_in = torch.from_numpy(x).to(dev)
     d_out = torch.empty((N, 2 * n * n), dtype=torch.float32, device=dev)
     stream = torch.cuda.current_stream(dev)
@@ -123,9 +166,7 @@ def main():
     elapsed = time.perf_counter() - t0
     gpu_ms = ev0.elapsed_time(ev1)
     if distributed:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        elapsed = reduce_max(elapsed, dist, dev)
 
     # parity spot check outside the timed region (the product path never touches the oracle)
     if rank == 0:

@@ -119,7 +119,10 @@ class GRiDCodeGenerator:
                                  "const int SUGGESTED_THREADS = " + str(self.suggested_threads) + ";",
                                  "const int GRID_MAX_SOLVES_PER_BLOCK = SUGGESTED_THREADS/GRID_LANES_PER_SOLVE; // what the *_DYNAMIC_SHARED_MEM_COUNT constants cover",
                                  "// per-solve LDS slice (elements of T) and the offsets of its parts",
-                                 "const int GRID_LDS_PER_SOLVE = " + str(lds["TOTAL"]) + ";"])
+                                 "const int GRID_LDS_PER_SOLVE = " + str(lds["TOTAL"]) + ";",
+                                 "const int GRID_OUT_PER_SOLVE = " + str(lds["OUT_PER_SOLVE"]) + "; // output staging per lane group, placed behind the block's slices",
+                                 "// a block of t threads needs (t/GRID_LANES_PER_SOLVE)*(GRID_LDS_PER_SOLVE+GRID_OUT_PER_SOLVE)*sizeof(T) bytes of dynamic LDS;",
+                                 "// the *_DYNAMIC_SHARED_MEM_COUNT constants below are that amount for SUGGESTED_THREADS"])
         for k in ("IN", "X", "U", "T", "MINV", "QDD", "F", "J"):
             self.gen_add_code_line("const int GRID_OFF_" + k + " = " + str(lds[k]) + ";")
         for k in ("ID", "MINV", "FD", "ID_DU", "FD_DU"):

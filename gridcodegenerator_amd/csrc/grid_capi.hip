@@ -31,6 +31,17 @@ static int fail(hipError_t e, const char *what) {
         if (e__ != hipSuccess) return fail(e__, #expr);  \
     } while (0)
 
+// dynamic LDS actually needed by a block of `threads` threads: one slice + one staging record per lane group.
+// (the *_DYNAMIC_SHARED_MEM_COUNT constants cover SUGGESTED_THREADS; smaller blocks must not reserve that much or
+//  they lose occupancy: measured 64.8 us vs 22.6 us per 16384-solve launch for 64-thread blocks)
+static inline size_t lds_bytes(const grid_handle *h) {
+    int threads = h->threads > 0 ? h->threads : grid::SUGGESTED_THREADS;
+    int gpb = threads / grid::GRID_LANES_PER_SOLVE;
+    if (gpb > grid::GRID_MAX_SOLVES_PER_BLOCK) gpb = grid::GRID_MAX_SOLVES_PER_BLOCK;
+    if (gpb < 1) gpb = 1;
+    return (size_t)gpb * (grid::GRID_LDS_PER_SOLVE + grid::GRID_OUT_PER_SOLVE) * sizeof(float);
+}
+
 static inline void launch_dims(const grid_handle *h, int num_timesteps, dim3 *grid, dim3 *block) {
     int threads = h->threads > 0 ? h->threads : grid::SUGGESTED_THREADS;
     int gpb = threads / grid::GRID_LANES_PER_SOLVE;
@@ -97,7 +108,7 @@ int grid_forward_dynamics_gradient_device(grid_handle *h, const float *d_q_qd_u,
     if (num_timesteps == 0) return 0;
     dim3 grid, block;
     launch_dims(h, num_timesteps, &grid, &block);
-    hipLaunchKernelGGL((grid::forward_dynamics_gradient_kernel<float>), grid, block, grid::FD_DU_DYNAMIC_SHARED_MEM_COUNT * sizeof(float),
+    hipLaunchKernelGGL((grid::forward_dynamics_gradient_kernel<float>), grid, block, lds_bytes(h),
                        (hipStream_t)stream, d_df_du, d_q_qd_u, stride_q_qd_u, h->d_robotModel, gravity, num_timesteps);
     GRID_TRY(hipGetLastError());
     return 0;
@@ -110,7 +121,7 @@ int grid_forward_dynamics_gradient_qdd_minv_device(grid_handle *h, const float *
     if (num_timesteps == 0) return 0;
     dim3 grid, block;
     launch_dims(h, num_timesteps, &grid, &block);
-    hipLaunchKernelGGL((grid::forward_dynamics_gradient_kernel<float>), grid, block, grid::FD_DU_DYNAMIC_SHARED_MEM_COUNT * sizeof(float),
+    hipLaunchKernelGGL((grid::forward_dynamics_gradient_kernel<float>), grid, block, lds_bytes(h),
                        (hipStream_t)stream, d_df_du, d_q_qd, stride_q_qd, d_qdd, d_Minv, h->d_robotModel, gravity, num_timesteps);
     GRID_TRY(hipGetLastError());
     return 0;
@@ -140,10 +151,10 @@ int grid_inverse_dynamics_device(grid_handle *h, const float *d_q_qd, int stride
     dim3 grid, block;
     launch_dims(h, num_timesteps, &grid, &block);
     if (d_qdd) {
-        hipLaunchKernelGGL((grid::inverse_dynamics_kernel<float>), grid, block, grid::ID_DYNAMIC_SHARED_MEM_COUNT * sizeof(float), (hipStream_t)stream,
+        hipLaunchKernelGGL((grid::inverse_dynamics_kernel<float>), grid, block, lds_bytes(h), (hipStream_t)stream,
                            d_c, d_q_qd, stride_q_qd, d_qdd, h->d_robotModel, gravity, num_timesteps);
     } else {
-        hipLaunchKernelGGL((grid::inverse_dynamics_kernel<float>), grid, block, grid::ID_DYNAMIC_SHARED_MEM_COUNT * sizeof(float), (hipStream_t)stream,
+        hipLaunchKernelGGL((grid::inverse_dynamics_kernel<float>), grid, block, lds_bytes(h), (hipStream_t)stream,
                            d_c, d_q_qd, stride_q_qd, h->d_robotModel, gravity, num_timesteps);
     }
     GRID_TRY(hipGetLastError());
@@ -156,7 +167,7 @@ int grid_direct_minv_device(grid_handle *h, const float *d_q, int stride_q, int 
     if (num_timesteps == 0) return 0;
     dim3 grid, block;
     launch_dims(h, num_timesteps, &grid, &block);
-    hipLaunchKernelGGL((grid::direct_minv_kernel<float>), grid, block, grid::MINV_DYNAMIC_SHARED_MEM_COUNT * sizeof(float), (hipStream_t)stream,
+    hipLaunchKernelGGL((grid::direct_minv_kernel<float>), grid, block, lds_bytes(h), (hipStream_t)stream,
                        d_Minv, d_q, stride_q, h->d_robotModel, num_timesteps);
     GRID_TRY(hipGetLastError());
     return 0;
@@ -168,7 +179,7 @@ int grid_forward_dynamics_device(grid_handle *h, const float *d_q_qd_u, int stri
     if (num_timesteps == 0) return 0;
     dim3 grid, block;
     launch_dims(h, num_timesteps, &grid, &block);
-    hipLaunchKernelGGL((grid::forward_dynamics_kernel<float>), grid, block, grid::FD_DYNAMIC_SHARED_MEM_COUNT * sizeof(float), (hipStream_t)stream,
+    hipLaunchKernelGGL((grid::forward_dynamics_kernel<float>), grid, block, lds_bytes(h), (hipStream_t)stream,
                        d_qdd, d_q_qd_u, stride_q_qd_u, h->d_robotModel, gravity, num_timesteps);
     GRID_TRY(hipGetLastError());
     return 0;
@@ -182,10 +193,10 @@ int grid_inverse_dynamics_gradient_device(grid_handle *h, const float *d_q_qd, i
     dim3 grid, block;
     launch_dims(h, num_timesteps, &grid, &block);
     if (d_qdd) {
-        hipLaunchKernelGGL((grid::inverse_dynamics_gradient_kernel<float>), grid, block, grid::ID_DU_DYNAMIC_SHARED_MEM_COUNT * sizeof(float),
+        hipLaunchKernelGGL((grid::inverse_dynamics_gradient_kernel<float>), grid, block, lds_bytes(h),
                            (hipStream_t)stream, d_dc_du, d_q_qd, stride_q_qd, d_qdd, h->d_robotModel, gravity, num_timesteps);
     } else {
-        hipLaunchKernelGGL((grid::inverse_dynamics_gradient_kernel<float>), grid, block, grid::ID_DU_DYNAMIC_SHARED_MEM_COUNT * sizeof(float),
+        hipLaunchKernelGGL((grid::inverse_dynamics_gradient_kernel<float>), grid, block, lds_bytes(h),
                            (hipStream_t)stream, d_dc_du, d_q_qd, stride_q_qd, h->d_robotModel, gravity, num_timesteps);
     }
     GRID_TRY(hipGetLastError());
@@ -202,7 +213,8 @@ int grid_forward_dynamics_gradient_single_timing(grid_handle *h, const float *h_
     struct timespec start, end;
     clock_gettime(CLOCK_MONOTONIC, &start);
     hipLaunchKernelGGL((grid::forward_dynamics_gradient_kernel_single_timing<float>), dim3(1), dim3(grid::GRID_LANES_PER_SOLVE < 64 ? 64 : grid::GRID_LANES_PER_SOLVE),
-                       grid::FD_DU_DYNAMIC_SHARED_MEM_COUNT * sizeof(float), 0, h->hd_data->d_df_du, h->hd_data->d_q_qd_u, 3 * n, h->d_robotModel, gravity, reps);
+                       (size_t)(64 / grid::GRID_LANES_PER_SOLVE > 0 ? 64 / grid::GRID_LANES_PER_SOLVE : 1) * (grid::GRID_LDS_PER_SOLVE + grid::GRID_OUT_PER_SOLVE) * sizeof(float),
+                       0, h->hd_data->d_df_du, h->hd_data->d_q_qd_u, 3 * n, h->d_robotModel, gravity, reps);
     GRID_TRY(hipGetLastError());
     GRID_TRY(hipDeviceSynchronize());
     clock_gettime(CLOCK_MONOTONIC, &end);

@@ -103,8 +103,8 @@ def gen_kernel_prologue(self, lds_per_solve_const):
         "int gpb = (blockDim.x*blockDim.y) / GRID_LANES_PER_SOLVE; if (gpb > GRID_MAX_SOLVES_PER_BLOCK) {gpb = GRID_MAX_SOLVES_PER_BLOCK;}",
         "if (grp >= gpb) {return;}",
         "T *s_mem = reinterpret_cast<T *>(grid_smem_raw) + grp*" + lds_per_solve_const + ";",
-        "// output staging lives behind all slices so that the records of a wave's lane groups are contiguous",
-        "T *s_out_all = reinterpret_cast<T *>(grid_smem_raw) + GRID_MAX_SOLVES_PER_BLOCK*" + lds_per_solve_const + ";",
+        "// output staging lives behind this block's slices so that the records of a wave's lane groups are contiguous",
+        "T *s_out_all = reinterpret_cast<T *>(grid_smem_raw) + gpb*" + lds_per_solve_const + ";",
     ])
 
 
