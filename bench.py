@@ -45,12 +45,13 @@ def cpu_baseline(robot, x, budget_s=12.0):
     except Exception:
         so = None
     orc = rbd_oracle.Oracle(robot, dtype=np.float32, lib_path=so)
-    sample = x[:2048]
+    sample = x  # the whole bench batch per call (enough work per thread for the static OpenMP split)
     orc.fd_grad_batch(sample, nthreads=0)  # warm
     t0 = time.perf_counter()
     _, cores = orc.fd_grad_batch(sample, nthreads=0)
-    dt = time.perf_counter() - t0
-    reps = max(1, min(100000, int(budget_s / max(dt, 1e-6))))
+    orc.fd_grad_batch(sample, nthreads=0)
+    dt = (time.perf_counter() - t0) / 2
+    reps = max(1, min(2000, int(budget_s / max(dt, 1e-6))))
     t0 = time.perf_counter()
     for _ in range(reps):
         orc.fd_grad_batch(sample, nthreads=0)
