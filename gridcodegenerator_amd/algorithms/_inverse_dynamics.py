@@ -17,10 +17,14 @@ def gen_tree_traversal(self, pre_fn, post_fn):
 
     def visit(i):
         self.gen_add_code_line("{ // joint " + str(i) + (" (root)" if m.parent[i] == -1 else " (parent " + str(m.parent[i]) + ")"), True)
+        self._cur_joint = i
         pre_fn(i)
+        self._cur_joint = None
         for ch in m.children[i]:
             visit(ch)
+        self._cur_joint = i
         post_fn(i)
+        self._cur_joint = None
         self.gen_add_end_control_flow()
 
     for r in m.roots:

@@ -10,6 +10,11 @@ hand-off goes through LDS followed by a wave-level sync (no s_barrier).
 
 
 def gen_add_code_line(self, new_code_line, add_indent_after=False):
+    cur = getattr(self, "_cur_joint", None)
+    if cur is not None and "grid_x" in new_code_line:
+        # inside a joint's code block the joint transform calls bind to that joint's sparsity-specialised functions
+        for op in ("grid_xmul(", "grid_xtmul_peq(", "grid_xtmul("):
+            new_code_line = new_code_line.replace(op, op[:-1] + "_" + str(cur) + "(")
     self.code_str += self.indent_level * "    " + new_code_line + "\n"
     if add_indent_after:
         self.indent_level += 1

@@ -147,6 +147,37 @@ def gen_spatial_algebra_helpers(self):
     self.gen_add_code_line("")
     m = self.model
     C = lambda x: "static_cast<T>(" + _lit(x) + ")"
+    ZERO = "static_cast<T>(0)"
+    for i in range(m.n):
+        PE, PB = m.X_pattern[i]
+        nnz = 2 * int(PE.sum()) + int(PB.sum())
+        self.gen_add_code_line("// joint %d transform products, specialised to the %d of 27 block entries of X_%d(q) that can be non-zero" % (i, nnz, i))
+        # y = X v
+        self.gen_add_code_line("template <typename T>")
+        self.gen_add_code_line("__device__ __forceinline__ void grid_xmul_%d(T (&y)[6], const T (&X)[18], const T (&v)[6]) {" % i, True)
+        for r in range(3):
+            top = ["X[%d]*v[%d]" % (3 * r + c, c) for c in range(3) if PE[r, c]]
+            bot = ["X[%d]*v[%d]" % (9 + 3 * r + c, c) for c in range(3) if PB[r, c]] + ["X[%d]*v[%d]" % (3 * r + c, 3 + c) for c in range(3) if PE[r, c]]
+            self.gen_add_code_line("y[%d] = %s; y[%d] = %s;" % (r, " + ".join(top) if top else ZERO, r + 3, " + ".join(bot) if bot else ZERO))
+        self.gen_add_end_function()
+        # y (+)= X^T f
+        for peq in (False, True):
+            self.gen_add_code_line("template <typename T>")
+            self.gen_add_code_line("__device__ __forceinline__ void grid_xtmul%s_%d(T (&y)[6], const T (&X)[18], const T (&f)[6]) {" % ("_peq" if peq else "", i), True)
+            for r in range(3):
+                top = ["X[%d]*f[%d]" % (3 * k + r, k) for k in range(3) if PE[k, r]] + ["X[%d]*f[%d]" % (9 + 3 * k + r, 3 + k) for k in range(3) if PB[k, r]]
+                bot = ["X[%d]*f[%d]" % (3 * k + r, 3 + k) for k in range(3) if PE[k, r]]
+                if peq:
+                    line = ""
+                    if top:
+                        line += "y[%d] += %s; " % (r, " + ".join(top))
+                    if bot:
+                        line += "y[%d] += %s;" % (r + 3, " + ".join(bot))
+                    if line:
+                        self.gen_add_code_line(line)
+                else:
+                    self.gen_add_code_line("y[%d] = %s; y[%d] = %s;" % (r, " + ".join(top) if top else ZERO, r + 3, " + ".join(bot) if bot else ZERO))
+            self.gen_add_end_function()
     for i in range(m.n):
         I = m.I[i]
         rb = _rigid_body_params(I)

@@ -395,6 +395,10 @@ class DuckRobot:
             for qt in (0.7, -1.3):
                 if not np.allclose(self.X(j, qt), np.asarray(f(qt), dtype=float).reshape(6, 6), atol=1e-9):
                     raise ValueError("joint %d: X(q) is not X_J(q)*X(0) for a principal-axis joint" % j)
+        # structural zeros of the tree transforms (|x| < 1e-12, e.g. cos(pi/2) = 6e-17 from URDF rpy's) are made exact so that the
+        # generator can emit sparsity-specialised transform products; the nonzero pattern of X(q) = X_J(q) X_tree follows from them
+        self.X_tree = [np.where(np.abs(X) < 1e-12, 0.0, X) for X in self.X_tree]
+        self.X_pattern = [self._x_pattern(j) for j in range(n)]
         Imats = robot.get_Imats_ordered_by_id()
         self.I = [np.asarray(Imats[j + 1], dtype=float).reshape(6, 6) for j in range(n)]
         self.damping = [float(robot.get_damping_by_id(j)) if hasattr(robot, "get_damping_by_id") else 0.0 for j in range(n)]
@@ -415,6 +419,27 @@ class DuckRobot:
                 raise ValueError("joint ids must be in DFS pre-order (contiguous subtrees)")
         self.roots = [j for j in range(n) if self.parent[j] == -1]
         self.depth = [len(a) for a in self.ancestors]
+
+    def _x_pattern(self, j):
+        """(E_nz, B_nz): 3x3 boolean masks of the entries of X_j(q) = [[E,0],[B,E]] that can be non-zero for some q."""
+        XT = self.X_tree[j]
+        E, B = XT[:3, :3], XT[3:, :3]
+        s = self.S_index[j]
+        a = s % 3
+        r1, r2 = (a + 1) % 3, (a + 2) % 3
+        PE, PB = np.zeros((3, 3), bool), np.zeros((3, 3), bool)
+        for c in range(3):
+            if s < 3:  # revolute: rows r1, r2 of E and of B are mixed by cos/sin, row a is constant
+                PE[r1, c] = PE[r2, c] = (E[r1, c] != 0) or (E[r2, c] != 0)
+                PE[a, c] = E[a, c] != 0
+                PB[r1, c] = PB[r2, c] = (B[r1, c] != 0) or (B[r2, c] != 0)
+                PB[a, c] = B[a, c] != 0
+            else:      # prismatic: E is constant, rows r1, r2 of B pick up q * rows r2, r1 of E
+                PE[:, c] = E[:, c] != 0
+                PB[r1, c] = (B[r1, c] != 0) or (E[r2, c] != 0)
+                PB[r2, c] = (B[r2, c] != 0) or (E[r1, c] != 0)
+                PB[a, c] = B[a, c] != 0
+        return PE, PB
 
     def X_joint(self, j, q):
         si = self.S_index[j]
