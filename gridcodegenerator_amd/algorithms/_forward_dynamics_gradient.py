@@ -30,32 +30,10 @@ def gen_forward_dynamics_gradient_inner_python(self, use_thread_group=False, use
     n = self.model.n
     if not use_qdd_Minv_input:
         self.gen_forward_dynamics_inner_function_call(use_thread_group)  # Minv, c, qdd (v is recomputed below inside the fused gradient walk)
-    C = self.cols_per_lane
-    H = self.lanes_per_solve // 2
-    self.gen_add_code_line(("T dc_dq[%d], dc_dqd[%d];" % (n, n)) if C == 2 else ("T dc_du[%d];" % n))
+    self.gen_add_code_line(self.gen_gradient_outputs_decl())
     self.gen_inverse_dynamics_gradient_inner_function_call(use_thread_group)
-    self.gen_add_code_line("// finally df/du = -Minv*dc/du: this lane's column(s) (Minv is read wave-uniformly from LDS)")
-    if C == 2:
-        self.gen_add_code_line("if (lane < %d) {" % n, True)
-        self.gen_add_code_line("#pragma unroll")
-        self.gen_add_code_line("for (int row = 0; row < %d; row++) {" % n, True)
-        self.gen_add_code_line("T vq = static_cast<T>(0); T vd = static_cast<T>(0);")
-        self.gen_add_code_line("#pragma unroll")
-        self.gen_add_code_line("for (int i = 0; i < %d; i++) { const T mv = s_Minv[row*%d + i]; vq += mv*dc_dq[i]; vd += mv*dc_dqd[i]; }" % (n, n))
-        self.gen_add_code_line("%s[lane*%d + row] = -vq; %s[%d + lane*%d + row] = -vd;" % (s_df_du_name, n, s_df_du_name, n * n, n))
-        self.gen_add_end_control_flow()
-        self.gen_add_end_control_flow()
-    else:
-        self.gen_add_code_line("if ((lane & %d) < %d) {" % (H - 1, n), True)
-        self.gen_add_code_line("const int col = (lane & %d) + ((lane >= %d) ? %d : 0);" % (H - 1, H, n))
-        self.gen_add_code_line("#pragma unroll")
-        self.gen_add_code_line("for (int row = 0; row < %d; row++) {" % n, True)
-        self.gen_add_code_line("T val = static_cast<T>(0);")
-        self.gen_add_code_line("#pragma unroll")
-        self.gen_add_code_line("for (int i = 0; i < %d; i++) { val += s_Minv[row*%d + i]*dc_du[i]; }" % (n, n))
-        self.gen_add_code_line("%s[col*%d + row] = -val;" % (s_df_du_name, n))
-        self.gen_add_end_control_flow()
-        self.gen_add_end_control_flow()
+    self.gen_add_code_line("// finally df/du = -Minv*dc/du for the column(s) this lane owns (Minv is read wave-uniformly from LDS)")
+    self.gen_dc_du_to_lds(s_df_du_name, minv_name="s_Minv")
 
 
 def gen_forward_dynamics_gradient_device(self, use_thread_group=False, use_qdd_Minv_input=False):

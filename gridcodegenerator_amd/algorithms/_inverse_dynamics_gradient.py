@@ -37,61 +37,81 @@ def gen_inverse_dynamics_gradient_kernel_max_temp_mem_size(self):
     return 0
 
 
+def gen_gradient_slots(self):
+    """Column -> (slot, lane) map of the derivative walk.  Columns are ordered by the joint they belong to
+    (c = 2*joint + is_qd: q0, qd0, q1, qd1, ...); slot s of lane l holds column c = s*G + l.  A column is structurally zero at
+    link k unless its joint is an ancestor of k or k itself, so ordering the columns by joint lets whole slots be skipped
+    at generation time for the links where none of their columns is live (chain: the late joints' slot is dead for the
+    first links; trees: a slot that only holds another limb's columns is dead for the whole limb)."""
+    m = self.model
+    n, G, C = m.n, self.lanes_per_solve, self.cols_per_lane
+    slots = []
+    for s_ in range(C):
+        lo, hi = (s_ * G) // 2, min(n, ((s_ + 1) * G) // 2)  # joints whose two columns live in this slot
+        if lo >= hi:
+            continue
+        joints = set(range(lo, hi))
+        live = [bool(joints & set(m.ancestors[k] + [k])) for k in range(n)]       # forward quantities (dv, da, df)
+        live_w = [bool(joints & set(m.subtree[k])) for k in range(n)]             # backward correction vector w
+        slots.append(dict(name="abcd"[s_], index=s_, lo=lo, hi=hi, live=live, live_w=live_w))
+    return slots
+
+
 def gen_inverse_dynamics_gradient_inner_function_call(self, use_thread_group=False, updated_var_names=None):
-    if self.cols_per_lane == 2:
-        self.gen_add_code_line("inverse_dynamics_gradient_inner<T>(dc_dq, dc_dqd, s_qd, s_qdd, s_X, s_F, s_J, gravity, lane);")
-    else:
-        self.gen_add_code_line("inverse_dynamics_gradient_inner<T>(dc_du, s_qd, s_qdd, s_X, s_F, s_J, gravity, lane);")
+    outs = ", ".join("dc_" + sl["name"] for sl in self.gen_gradient_slots())
+    self.gen_add_code_line("inverse_dynamics_gradient_inner<T>(" + outs + ", s_qd, s_qdd, s_X, s_F, s_J, gravity, lane);")
+
+
+def gen_gradient_outputs_decl(self):
+    n = self.model.n
+    return "T " + ", ".join("dc_%s[%d]" % (sl["name"], n) for sl in self.gen_gradient_slots()) + ";"
 
 
 def gen_inverse_dynamics_gradient_inner(self, use_thread_group=False):
     m = self.model
     n = m.n
-    C = self.cols_per_lane
-    H = self.lanes_per_solve // 2
-    cols = ("q", "d") if C == 2 else ("u",)  # register name suffixes of the column(s) a lane owns
-    notes = ["v, a, f of the RNEA pass with qdd are recomputed wave-uniformly inside the same tree walk",
-             "follows /root/reference/_test.py:229-494 incl. the damping term on diag(dc/dqd)"]
-    if C == 2:
-        notes.insert(0, "dc_dq[i] = d c_i / d q_lane and dc_dqd[i] = d c_i / d qd_lane for i = 0..n-1 (zero for lanes >= n)")
-        outs = "T (&dc_dq)[%d], T (&dc_dqd)[%d]" % (n, n)
-    else:
-        notes.insert(0, "dc_du[i] = d c_i / d q_lane for lanes < %d and d c_i / d qd_(lane-%d) for lanes >= %d" % (H, H, H))
-        outs = "T (&dc_du)[%d]" % n
-    self.gen_add_func_doc("Computes the gradient of inverse dynamics (this lane's column(s))", notes,
-                          ["dc_* are the register outputs", "s_qd is the vector of joint velocities in LDS",
+    G = self.lanes_per_solve
+    slots = self.gen_gradient_slots()
+    ZERO, ONE = "static_cast<T>(0)", "static_cast<T>(1)"
+    self.gen_add_func_doc("Computes the gradient of inverse dynamics (the derivative columns this lane owns)",
+                          ["columns are ordered c = 2*joint + is_qd; slot s of lane l owns column c = s*GRID_LANES_PER_SOLVE + l and returns",
+                           "dc_<slot>[i] = d c_i / d u_c  (u_c = q_joint or qd_joint); columns c >= 2*NUM_JOINTS return zeros",
+                           "v, a, f of the RNEA pass with qdd are recomputed wave-uniformly inside the same tree walk",
+                           "follows /root/reference/_test.py:229-494 incl. the damping term on diag(dc/dqd)"],
+                          ["dc_* are the register outputs (one array per slot)", "s_qd is the vector of joint velocities in LDS",
                            "s_qdd is the vector of joint accelerations in LDS", "s_X is this solve's compact X(q) storage",
-                           "s_F is LDS scratch for the wave-uniform link forces (8 floats per joint)",
-                           "s_J is LDS scratch for the velocity Jacobian columns of the current link (8 floats per joint)",
+                           "s_F is LDS scratch for the wave-uniform link forces (6 floats per joint)",
+                           "s_J is LDS scratch for the velocity Jacobian columns of the current link (double buffered)",
                            "gravity is the gravity constant", "lane is the caller's lane index inside the solve's lane group"], None)
     self.gen_add_code_line("template <typename T>")
     self.gen_add_code_line("__device__ __forceinline__")
-    self.gen_add_code_line("void inverse_dynamics_gradient_inner(" + outs + ", const T *s_qd, const T *s_qdd, const T *s_X, T *s_F, T *s_J, const T gravity, const int lane) {", True)
-    ZERO, ONE = "static_cast<T>(0)", "static_cast<T>(1)"
-    if C == 2:
-        self.gen_add_code_line("const int jcol = lane; // joint whose two columns this lane owns")
-        dcs = {"q": "dc_dq", "d": "dc_dqd"}
-    else:
-        self.gen_add_code_line("const int jcol = lane & %d; const bool is_qd = lane >= %d; // column owned by this lane" % (H - 1, H))
-        dcs = {"u": "dc_du"}
+    self.gen_add_code_line("void inverse_dynamics_gradient_inner(" + ", ".join("T (&dc_%s)[%d]" % (sl["name"], n) for sl in slots) +
+                           ", const T *s_qd, const T *s_qdd, const T *s_X, T *s_F, T *s_J, const T gravity, const int lane) {", True)
+    self.gen_add_code_line("const bool is_qd = (lane & 1) != 0; // odd columns are d/dqd, even columns d/dq")
+    for sl in slots:
+        self.gen_add_code_line("const int jc_%s = (%d + lane) >> 1; // joint of the column this lane owns in slot %s" % (sl["name"], sl["index"] * G, sl["name"]))
     self.gen_add_code_line("#pragma unroll")
-    self.gen_add_code_line("for (int i = 0; i < %d; i++) { %s }" % (n, " ".join(d + "[i] = " + ZERO + ";" for d in dcs.values())))
+    self.gen_add_code_line("for (int i = 0; i < %d; i++) { %s }" % (n, " ".join("dc_%s[i] = %s;" % (sl["name"], ZERO) for sl in slots)))
+    jstride = (6 * n + 3) // 4 * 4
 
     def pre(k):
         s, p = m.S_index[k], m.parent[k]
         K, P = str(k), str(p)
-        jbuf = (m.depth[k] & 1) * ((6 * n + 3) // 4 * 4)  # s_J is double buffered by depth parity: no hand-off sync is needed after the dots
-        if C == 2:
-            self.gen_add_code_line("const T self_%s = (jcol == %s) ? %s : %s;" % (K, K, ONE, ZERO))
-            selq, seld = "self_" + K, "self_" + K
-        else:
-            self.gen_add_code_line("const T selq_%s = (jcol == %s && !is_qd) ? %s : %s; const T seld_%s = (jcol == %s && is_qd) ? %s : %s;" % (K, K, ONE, ZERO, K, K, ONE, ZERO))
-            selq, seld = "selq_" + K, "seld_" + K
-        decl = ["v_%s[6]" % K, "a_%s[6]" % K, "w_%s[6]" % K]
-        for c in cols:
-            decl += ["dv%s_%s[6]" % (c, K), "da%s_%s[6]" % (c, K)]
+        jbuf = (m.depth[k] & 1) * jstride  # s_J is double buffered by depth parity: no hand-off sync is needed after the dots
+        act = [sl for sl in slots if sl["live"][k]]
+        decl = ["v_%s[6]" % K, "a_%s[6]" % K]
+        for sl in act:
+            decl += ["dv%s_%s[6]" % (sl["name"], K), "da%s_%s[6]" % (sl["name"], K)]
+        for sl in slots:
+            if sl["live_w"][k]:
+                decl.append("w%s_%s[6]" % (sl["name"], K))
         self.gen_add_code_line("T " + ", ".join(decl) + ";")
-        self.gen_add_code_line("grid_zero6(w_%s);" % K)
+        for sl in slots:
+            if sl["live_w"][k]:
+                self.gen_add_code_line("grid_zero6(w%s_%s);" % (sl["name"], K))
+        own = [sl for sl in slots if sl["lo"] <= k < sl["hi"]][0]  # the slot that holds joint k's own two columns
+        self.gen_add_code_line("const T selq_%s = (jc_%s == %s && !is_qd) ? %s : %s; const T seld_%s = (jc_%s == %s && is_qd) ? %s : %s;" %
+                               (K, own["name"], K, ONE, ZERO, K, own["name"], K, ONE, ZERO))
         self.gen_add_code_line("{", True)
         self.gen_add_code_line("T X[18]; grid_load_X(X, &s_X[GRID_X_STRIDE*" + K + "]);")
         self.gen_add_code_line("const T qd = s_qd[" + K + "]; const T qdd = s_qdd[" + K + "];")
@@ -114,62 +134,58 @@ def gen_inverse_dynamics_gradient_inner(self, use_thread_group=False):
         self.gen_add_code_line("      #pragma unroll")
         self.gen_add_code_line("      for (int r = 0; r < 6; r++) { s_F[%d + r] = f[r]; }" % (6 * k))
         self.gen_add_code_line("  } }")
-        self.gen_add_code_line("// this lane's column(s): dv, da (forward recursions with the self terms of column == joint)")
-        if C == 2:
-            if p == -1:
+        self.gen_add_code_line("// derivative columns: dv, da (forward recursions; the self terms belong to the columns of joint %s, slot %s)" % (K, own["name"]))
+        for sl in act:
+            c = sl["name"]
+            is_own = sl is own
+            parent_live = p != -1 and sl["live"][p]
+            if parent_live:
+                self.gen_add_code_line("grid_xmul(dv%s_%s, X, dv%s_%s); grid_xmul(da%s_%s, X, da%s_%s);" % (c, K, c, P, c, K, c, P))
+                if is_own:
+                    self.gen_add_code_line("#pragma unroll")
+                    self.gen_add_code_line("for (int r = 0; r < 6; r++) { dv%s_%s[r] += selq_%s*Mxv[r]; da%s_%s[r] += selq_%s*MxXa[r] + seld_%s*Mxv[r]; }" % (c, K, K, c, K, K, K))
+                    self.gen_add_code_line("dv%s_%s[%d] += seld_%s;" % (c, K, s, K))
+            else:  # no live parent column in this slot: only the self terms (is_own is implied by liveness)
                 self.gen_add_code_line("#pragma unroll")
-                self.gen_add_code_line("for (int r = 0; r < 6; r++) { dvq_%s[r] = %s*Mxv[r]; dvd_%s[r] = %s; daq_%s[r] = %s*MxXa[r]; dad_%s[r] = %s*Mxv[r]; }" % (K, selq, K, ZERO, K, selq, K, seld))
-                self.gen_add_code_line("dvd_%s[%d] = %s;" % (K, s, seld))
-            else:
-                self.gen_add_code_line("grid_xmul(dvq_%s, X, dvq_%s); grid_xmul(dvd_%s, X, dvd_%s);" % (K, P, K, P))
-                self.gen_add_code_line("grid_xmul(daq_%s, X, daq_%s); grid_xmul(dad_%s, X, dad_%s);" % (K, P, K, P))
+                self.gen_add_code_line("for (int r = 0; r < 6; r++) { dv%s_%s[r] = selq_%s*Mxv[r]; da%s_%s[r] = selq_%s*MxXa[r] + seld_%s*Mxv[r]; }" % (c, K, K, c, K, K, K))
+                self.gen_add_code_line("dv%s_%s[%d] += seld_%s;" % (c, K, s, K))
+            self.gen_add_code_line("grid_mxS_peq<T,%d>(da%s_%s, dv%s_%s, qd);" % (s, c, K, c, K))
+        self.gen_add_code_line("// publish the velocity Jacobian columns J_{k,a} = d v_k / d qd_a (the d/dqd columns of dv) for the proper ancestors")
+        if m.ancestors[k]:
+            for sl in act:
+                if not any(sl["lo"] <= a < sl["hi"] for a in m.ancestors[k]):
+                    continue
+                c = sl["name"]
+                self.gen_add_code_line("if (is_qd && jc_%s < %d) {" % (c, n), True)
                 self.gen_add_code_line("#pragma unroll")
-                self.gen_add_code_line("for (int r = 0; r < 6; r++) { dvq_%s[r] += %s*Mxv[r]; daq_%s[r] += %s*MxXa[r]; dad_%s[r] += %s*Mxv[r]; }" % (K, selq, K, selq, K, seld))
-                self.gen_add_code_line("dvd_%s[%d] += %s;" % (K, s, seld))
-            self.gen_add_code_line("grid_mxS_peq<T,%d>(daq_%s, dvq_%s, qd); grid_mxS_peq<T,%d>(dad_%s, dvd_%s, qd);" % (s, K, K, s, K, K))
-        else:
-            if p == -1:
-                self.gen_add_code_line("#pragma unroll")
-                self.gen_add_code_line("for (int r = 0; r < 6; r++) { dvu_%s[r] = %s*Mxv[r]; dau_%s[r] = %s*MxXa[r] + %s*Mxv[r]; }" % (K, selq, K, selq, seld))
-                self.gen_add_code_line("dvu_%s[%d] += %s;" % (K, s, seld))
-            else:
-                self.gen_add_code_line("grid_xmul(dvu_%s, X, dvu_%s); grid_xmul(dau_%s, X, dau_%s);" % (K, P, K, P))
-                self.gen_add_code_line("#pragma unroll")
-                self.gen_add_code_line("for (int r = 0; r < 6; r++) { dvu_%s[r] += %s*Mxv[r]; dau_%s[r] += %s*MxXa[r] + %s*Mxv[r]; }" % (K, selq, K, selq, seld))
-                self.gen_add_code_line("dvu_%s[%d] += %s;" % (K, s, seld))
-            self.gen_add_code_line("grid_mxS_peq<T,%d>(dau_%s, dvu_%s, qd);" % (s, K, K))
-        self.gen_add_code_line("// publish the velocity Jacobian columns J_{k,a} = d v_k / d qd_a (the d/dqd columns of dv)")
-        if C == 2:
-            self.gen_add_code_line("if (lane < %d) {" % n, True)
-            self.gen_add_code_line("#pragma unroll")
-            self.gen_add_code_line("for (int r = 0; r < 6; r++) { s_J[%d + 6*lane + r] = dvd_%s[r]; }" % (jbuf, K))
-        else:
-            self.gen_add_code_line("if (is_qd && jcol < %d) {" % n, True)
-            self.gen_add_code_line("#pragma unroll")
-            self.gen_add_code_line("for (int r = 0; r < 6; r++) { s_J[%d + 6*jcol + r] = dvu_%s[r]; }" % (jbuf, K))
-        self.gen_add_end_control_flow()
+                self.gen_add_code_line("for (int r = 0; r < 6; r++) { s_J[%d + 6*jc_%s + r] = dv%s_%s[r]; }" % (jbuf, c, c, K))
+                self.gen_add_end_control_flow()
         self.gen_add_code_line("// local df = I da + fx(dv) (I v) + fx(v) (I dv), consumed at once: dc[a] += J_{k,a} . df for a in ancestors(k) + {k}")
-        for c in cols:
+        for sl in act:
+            c = sl["name"]
             self.gen_add_code_line("T df%s[6]; { T Idv[6]; grid_imul_%s(df%s, da%s_%s); grid_fxv_peq(df%s, dv%s_%s, Iv); grid_imul_%s(Idv, dv%s_%s); grid_fxv_peq(df%s, v_%s, Idv); }" % (c, K, c, c, K, c, c, K, K, c, K, c, K))
-        self.gen_add_sync(use_thread_group)
-        for a in m.ancestors[k] + [k]:
-            self.gen_add_code_line("{ T J[6];")
-            self.gen_add_code_line("  #pragma unroll")
-            self.gen_add_code_line("  for (int r = 0; r < 6; r++) { J[r] = s_J[%d + r]; }" % (jbuf + 6 * a))
-            self.gen_add_code_line("  " + " ".join("%s[%d] += grid_dot6(J, df%s); grid_pin(%s[%d]);" % (dcs[c], a, c, dcs[c], a) for c in cols) + " }")
+        self.gen_add_code_line("// J_{k,k} = S_k: no LDS round trip for the link's own row")
+        self.gen_add_code_line(" ".join("dc_%s[%d] += df%s[%d]; grid_pin(dc_%s[%d]);" % (sl["name"], k, sl["name"], s, sl["name"], k) for sl in act))
+        if m.ancestors[k]:
+            self.gen_add_sync(use_thread_group)
+            for a in m.ancestors[k]:
+                self.gen_add_code_line("{ T J[6];")
+                self.gen_add_code_line("  #pragma unroll")
+                self.gen_add_code_line("  for (int r = 0; r < 6; r++) { J[r] = s_J[%d + r]; }" % (jbuf + 6 * a))
+                self.gen_add_code_line("  " + " ".join("dc_%s[%d] += grid_dot6(J, df%s); grid_pin(dc_%s[%d]);" % (sl["name"], a, sl["name"], sl["name"], a) for sl in act) + " }")
         self.gen_add_end_control_flow()
 
     def post(k):
         s, p = m.S_index[k], m.parent[k]
         K, P = str(k), str(p)
         damp = m.damping[k]
-        qcol = "q" if C == 2 else "u"
-        selq = ("self_" if C == 2 else "selq_") + K
-        seld = ("self_" if C == 2 else "seld_") + K
+        own = [sl for sl in slots if sl["lo"] <= k < sl["hi"]][0]
         self.gen_add_code_line("// corrections that travelled up from the subtree: dc[k][col] -= S_k^T w")
-        self.gen_add_code_line("%s[%s] -= w_%s[%d];" % (dcs[qcol], K, K, s))
+        for sl in slots:
+            if sl["live_w"][k]:
+                self.gen_add_code_line("dc_%s[%s] -= w%s_%s[%d];" % (sl["name"], K, sl["name"], K, s))
         if damp != 0.0:
-            self.gen_add_code_line("%s[%s] += %s*static_cast<T>(%s);" % (dcs["d" if C == 2 else "u"], K, seld, repr(float(damp))))
+            self.gen_add_code_line("dc_%s[%s] += seld_%s*static_cast<T>(%s);" % (own["name"], K, K, repr(float(damp))))
         if p == -1 and k != m.roots[-1]:
             self.gen_add_sync(use_thread_group)  # the next root's subtree reuses the depth-0 J buffer
         if p != -1:
@@ -180,8 +196,11 @@ def gen_inverse_dynamics_gradient_inner(self, use_thread_group=False):
             self.gen_add_code_line("#pragma unroll")
             self.gen_add_code_line("for (int r = 0; r < 6; r++) { f[r] = s_F[%d + r]; fp[r] = s_F[%d + r]; }" % (6 * k, 6 * p))
             self.gen_add_code_line("// column == joint injects mxS(S, f_subtree); everything is carried to the parent frame")
-            self.gen_add_code_line("grid_mxS_peq<T,%d>(w_%s, f, %s);" % (s, K, selq))
-            self.gen_add_code_line("grid_xtmul_peq(fp, X, f); grid_xtmul_peq(w_%s, X, w_%s); grid_pin6(w_%s);" % (P, K, P))
+            self.gen_add_code_line("grid_mxS_peq<T,%d>(w%s_%s, f, selq_%s);" % (s, own["name"], K, K))
+            self.gen_add_code_line("grid_xtmul_peq(fp, X, f);")
+            for sl in slots:
+                if sl["live_w"][k]:
+                    self.gen_add_code_line("grid_xtmul_peq(w%s_%s, X, w%s_%s); grid_pin6(w%s_%s);" % (sl["name"], P, sl["name"], K, sl["name"], P))
             self.gen_add_code_line("if (lane == 0) {", True)
             self.gen_add_code_line("#pragma unroll")
             self.gen_add_code_line("for (int r = 0; r < 6; r++) { s_F[%d + r] = fp[r]; }" % (6 * p))
@@ -192,21 +211,25 @@ def gen_inverse_dynamics_gradient_inner(self, use_thread_group=False):
     self.gen_add_end_function()
 
 
-def gen_dc_du_to_lds(self, dst="s_dc_du", negate_minv=None):
-    """Emits the register -> LDS staging of this lane's column(s) in the device layout [col*n + row]."""
+def gen_dc_du_to_lds(self, dst="s_dc_du", minv_name=None):
+    """Emits the register -> LDS staging of this lane's column(s) in the device layout [col*n + row], col = joint + n*is_qd.
+    With minv_name set, the staged values are -Minv * dc (the forward-dynamics gradient) instead of dc itself."""
     n = self.model.n
-    C = self.cols_per_lane
-    H = self.lanes_per_solve // 2
-    if C == 2:
-        self.gen_add_code_line("if (lane < %d) {" % n, True)
+    G = self.lanes_per_solve
+    for sl in self.gen_gradient_slots():
+        c = sl["name"]
+        self.gen_add_code_line("if (%d + lane < %d) {" % (sl["index"] * G, 2 * n), True)
+        self.gen_add_code_line("const int col = ((%d + lane) >> 1) + (((lane & 1) != 0) ? %d : 0);" % (sl["index"] * G, n))
         self.gen_add_code_line("#pragma unroll")
-        self.gen_add_code_line("for (int row = 0; row < %d; row++) { %s[lane*%d + row] = dc_dq[row]; %s[%d + lane*%d + row] = dc_dqd[row]; }" % (n, dst, n, dst, n * n, n))
-        self.gen_add_end_control_flow()
-    else:
-        self.gen_add_code_line("if ((lane & %d) < %d) {" % (H - 1, n), True)
-        self.gen_add_code_line("const int col = (lane & %d) + ((lane >= %d) ? %d : 0);" % (H - 1, H, n))
-        self.gen_add_code_line("#pragma unroll")
-        self.gen_add_code_line("for (int row = 0; row < %d; row++) { %s[col*%d + row] = dc_du[row]; }" % (n, dst, n))
+        if minv_name is None:
+            self.gen_add_code_line("for (int row = 0; row < %d; row++) { %s[col*%d + row] = dc_%s[row]; }" % (n, dst, n, c))
+        else:
+            self.gen_add_code_line("for (int row = 0; row < %d; row++) {" % n, True)
+            self.gen_add_code_line("T val = static_cast<T>(0);")
+            self.gen_add_code_line("#pragma unroll")
+            self.gen_add_code_line("for (int i = 0; i < %d; i++) { val += %s[row*%d + i]*dc_%s[i]; }" % (n, minv_name, n, c))
+            self.gen_add_code_line("%s[col*%d + row] = -val;" % (dst, n))
+            self.gen_add_end_control_flow()
         self.gen_add_end_control_flow()
 
 
@@ -245,7 +268,7 @@ def gen_inverse_dynamics_gradient_kernel(self, use_thread_group=False, use_qdd_i
         self.gen_add_code_line("for (int rep = 0; rep < NUM_TIMESTEPS; rep++){", True)
     self.gen_add_code_line("// compute")
     self.gen_load_update_XImats_helpers_function_call(use_thread_group)
-    self.gen_add_code_line(("T dc_dq[%d], dc_dqd[%d];" % (n, n)) if self.cols_per_lane == 2 else ("T dc_du[%d];" % n))
+    self.gen_add_code_line(self.gen_gradient_outputs_decl())
     self.gen_inverse_dynamics_gradient_inner_function_call(use_thread_group)
     self.gen_dc_du_to_lds("s_dc_du")
     if single_call_timing:
