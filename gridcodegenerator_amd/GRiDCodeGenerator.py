@@ -21,14 +21,14 @@ class GRiDCodeGenerator:
         gen_add_func_doc, gen_add_serial_ops, gen_add_parallel_loop, gen_add_sync, gen_var_in_list, gen_var_not_in_list, \
         gen_lane_mask_test, gen_kernel_prologue, gen_kernel_load_inputs, gen_kernel_save_result, gen_kernel_save_result_single_timing, \
         gen_spatial_algebra_helpers, gen_mx_func_call_for_cpp, \
-        gen_lds_layout, gen_get_XI_size, gen_topology_helpers_size, gen_init_XImats, gen_init_topology_helpers, gen_init_robotModel, \
+        gen_lds_layout, gen_model_constant_table, gen_get_XI_size, gen_topology_helpers_size, gen_init_XImats, gen_init_topology_helpers, gen_init_robotModel, \
         gen_load_update_XImats_helpers_function_call, gen_load_update_XImats_helpers, gen_topology_sparsity_helpers_python
 
     # algorithms on the forward-dynamics-gradient path
     from .algorithms import gen_tree_traversal, \
         gen_inverse_dynamics_inner_temp_mem_size, gen_inverse_dynamics_inner_function_call, gen_inverse_dynamics_inner, \
         gen_inverse_dynamics_kernel, gen_inverse_dynamics_host, gen_inverse_dynamics, \
-        gen_direct_minv_inner_temp_mem_size, gen_direct_minv_inner_function_call, gen_direct_minv_inner, \
+        gen_direct_minv_inner_temp_mem_size, gen_direct_minv_inner_function_call, gen_direct_minv_inner, gen_direct_minv_inner_header, gen_direct_minv_inner_body, \
         gen_direct_minv_kernel, gen_direct_minv_host, gen_direct_minv, \
         gen_forward_dynamics_inner_temp_mem_size, gen_forward_dynamics_finish_function_call, gen_forward_dynamics_finish, \
         gen_forward_dynamics_inner_function_call, gen_forward_dynamics_inner, gen_forward_dynamics_kernel, \
@@ -45,6 +45,7 @@ class GRiDCodeGenerator:
         self.model = DuckRobot(robotObj)  # numeric tables; raises for robots outside the supported joint models
         self.code_str = ""
         self.indent_level = 0
+        self._cur_joint = None
         self.DEBUG_MODE = DEBUG_MODE
         self.gen_print_mat = DEBUG_MODE or NEED_PRINT_MAT
         self.use_dynamic_shared_mem_flag = True  # the lane-group kernels always carve their LDS slice from dynamic LDS
@@ -255,6 +256,7 @@ class GRiDCodeGenerator:
         self.gen_add_code_line("namespace " + self.file_namespace + " {", True)
         self.gen_add_constants_helpers(include_base_inertia, include_homogenous_transforms)
         self.gen_spatial_algebra_helpers()
+        self.gen_model_constant_table()
         self.gen_init_topology_helpers()
         self.gen_init_XImats(include_base_inertia, include_homogenous_transforms)
         self.gen_init_robotModel()

@@ -27,9 +27,20 @@ def gen_direct_minv_inner_function_call(self, use_thread_group=False, updated_va
     self.gen_add_sync(use_thread_group)
 
 
-def gen_direct_minv_inner(self, use_thread_group=False):
+def gen_direct_minv_inner(self, use_thread_group=False, body_only=False, bwd_hook=None, fwd_hook=None):
+    """body_only: emit just the function body (the fused forward_dynamics_inner supplies the header); bwd_hook(idx) is called once
+    per backward-sweep joint inside the region that waits for U (independent work placed there hides the LDS round trip);
+    fwd_hook() is called after the forward sweep, before M^-1 is published."""
     m = self.model
     n = m.n
+    if not body_only:
+        self.gen_direct_minv_inner_header()
+    self.gen_direct_minv_inner_body(use_thread_group, bwd_hook, fwd_hook)
+    if not body_only:
+        self.gen_add_end_function()
+
+
+def gen_direct_minv_inner_header(self):
     self.gen_add_func_doc("Compute the inverse of the mass matrix (dense, symmetric) into LDS",
                           ["follows /root/reference/_test.py:117-226; lane j produces column j (and, by symmetry, row j)",
                            "the caller must grid_wave_sync() before other lanes' entries of s_Minv are read"],
@@ -41,6 +52,12 @@ def gen_direct_minv_inner(self, use_thread_group=False):
     self.gen_add_code_line("template <typename T>")
     self.gen_add_code_line("__device__ __forceinline__")
     self.gen_add_code_line("void direct_minv_inner(T *s_Minv, const T *s_X, T *s_U, T *s_T, const robotModel<T> *d_robotModel, const int lane) {", True)
+
+
+def gen_direct_minv_inner_body(self, use_thread_group=False, bwd_hook=None, fwd_hook=None):
+    m = self.model
+    n = m.n
+    bwd_count = [0]
     IA0 = 0 if self.cols_per_lane == 2 else self.lanes_per_solve // 2  # first of the 6 lanes that carry the articulated-inertia columns
     shared = IA0 != 0  # F lanes and IA lanes are disjoint: one X^T product serves both
     if IA0 == 0:
@@ -49,7 +66,7 @@ def gen_direct_minv_inner(self, use_thread_group=False):
     else:
         self.gen_add_code_line("const int cI = (lane < %d) ? 0 : ((lane > %d) ? 5 : (lane - %d)); // articulated-inertia column owned by this lane (lanes %d..%d are live)" % (IA0, IA0 + 5, IA0, IA0, IA0 + 5))
         self.gen_add_code_line("const bool isIA = (lane >= %d) && (lane < %d);" % (IA0, IA0 + 6))
-    self.gen_add_code_line("const T *d_I = &d_robotModel->d_XImats[" + str(18 * n) + " + 6*cI];")
+    self.gen_add_code_line("const T *d_I = &grid_model_constants(static_cast<const T *>(nullptr))[" + str(18 * n) + " + 6*cI]; (void)d_robotModel;")
     self.gen_add_code_line("T Mcol[" + str(n) + "];")
     self.gen_add_code_line("//")
     self.gen_add_code_line("// backward sweep (post-order): U, D^-1, Minv row updates, F and IA propagation to the parent")
@@ -76,6 +93,11 @@ def gen_direct_minv_inner(self, use_thread_group=False):
         self.gen_add_code_line("if (lane == 0) { s_U[%d] = Dinv; }" % (8 * i + 6))
         self.gen_add_code_line("const T m = ((lane == %d) ? Dinv : static_cast<T>(0)) - Dinv*F_%d[%d];" % (i, i, s))
         self.gen_add_code_line("Mcol[%d] = m; grid_pin(Mcol[%d]);" % (i, i))
+        if bwd_hook is not None:
+            saved = self._cur_joint
+            bwd_hook(bwd_count[0])
+            self._cur_joint = saved
+            bwd_count[0] += 1
         if p != -1:
             self.gen_add_code_line("T X[18]; grid_load_X(X, &s_X[GRID_X_STRIDE*%d]);" % i)
             self.gen_add_code_line("#pragma unroll")
@@ -136,12 +158,13 @@ def gen_direct_minv_inner(self, use_thread_group=False):
         pass
 
     self.gen_tree_traversal(pre_f, post_f)
+    if fwd_hook is not None:
+        fwd_hook()
     self.gen_add_code_line("// publish: lane j writes the upper-triangle entries of its column and their mirror images")
     self.gen_add_code_line("if (lane < %d) {" % n, True)
     for i in range(n):
         self.gen_add_code_line("if (lane >= %d) { s_Minv[%d + lane] = Mcol[%d]; s_Minv[lane*%d + %d] = Mcol[%d]; }" % (i, i * n, i, n, i, i))
     self.gen_add_end_control_flow()
-    self.gen_add_end_function()
 
 
 def gen_direct_minv_kernel(self, use_thread_group=False, single_call_timing=False):

@@ -39,8 +39,13 @@ def gen_forward_dynamics_inner_function_call(self, use_thread_group=False, updat
 
 
 def gen_forward_dynamics_inner(self, use_thread_group=False):
-    n = self.model.n
-    self.gen_add_func_doc("Computes forward dynamics", ["direct_minv_inner + inverse_dynamics_inner(qdd = 0) + forward_dynamics_finish; s_qdd and s_Minv are valid for all lanes on return"],
+    """Fused M^-1 + RNEA(qdd = 0) + finish.  The two algorithms are independent until qdd = M^-1 (u - c), and the M^-1 backward sweep
+    is a chain of LDS round trips (U publish -> read, transpose write -> read) with little arithmetic in between, so the
+    wave-uniform RNEA forward steps are emitted INSIDE those regions (one link per M^-1 joint) where they fill the latency
+    bubbles; the RNEA backward steps share the region of the M^-1 forward sweep."""
+    m = self.model
+    n = m.n
+    self.gen_add_func_doc("Computes forward dynamics", ["fused direct_minv_inner + inverse_dynamics_inner(qdd = 0) + forward_dynamics_finish; s_qdd and s_Minv are valid for all lanes on return"],
                           ["s_qdd is a pointer to LDS for the final result", "s_qd is the vector of joint velocities", "s_u is the vector of joint input torques",
                            "s_X is this solve's compact X(q) storage", "s_U, s_T are LDS scratch (see direct_minv_inner)", "s_Minv receives the dense inverse mass matrix",
                            "d_robotModel is the pointer to the initialized model specific helpers on the GPU", "gravity is the gravity constant",
@@ -48,9 +53,46 @@ def gen_forward_dynamics_inner(self, use_thread_group=False):
     self.gen_add_code_line("template <typename T>")
     self.gen_add_code_line("__device__ __forceinline__")
     self.gen_add_code_line("void forward_dynamics_inner(T *s_qdd, const T *s_qd, const T *s_u, const T *s_X, T *s_U, T *s_T, T *s_Minv, const robotModel<T> *d_robotModel, const T gravity, const int lane) {", True)
-    self.gen_direct_minv_inner_function_call(use_thread_group)
     self.gen_add_code_line("T c[%d];" % n)
-    self.gen_inverse_dynamics_inner_function_call(use_thread_group, True, False)
+    import os
+    if os.environ.get("GRID_FUSE_FD", "1") == "0":  # tuning knob: the unfused sequence (M^-1, then RNEA, then finish)
+        self.gen_direct_minv_inner_function_call(use_thread_group)
+        self.gen_inverse_dynamics_inner_function_call(use_thread_group, True, False)
+        self.gen_forward_dynamics_finish_function_call(use_thread_group)
+        self.gen_add_end_function()
+        return
+    self.gen_add_code_line("T rv[%d][6], ra[%d][6], rf[%d][6]; // RNEA link vectors (wave-uniform)" % (n, n, n))
+    order = []  # RNEA forward order = pre-order = joint id order
+
+    def rnea_fwd_step(idx):
+        j = idx  # ids are DFS pre-order: parents come first
+        s, p = m.S_index[j], m.parent[j]
+        self._cur_joint = j
+        self.gen_add_code_line("{ // RNEA forward step of link %d, placed here to overlap the LDS round trips of the M^-1 sweep" % j, True)
+        self.gen_add_code_line("T X[18]; grid_load_X(X, &s_X[GRID_X_STRIDE*%d]);" % j)
+        self.gen_add_code_line("const T qd_r = s_qd[%d];" % j)
+        if p == -1:
+            self.gen_add_code_line("grid_zero6(rv[%d]); rv[%d][%d] = qd_r;" % (j, j, s))
+            self.gen_add_code_line("grid_zero6(ra[%d]); ra[%d][3] = X[2]*gravity; ra[%d][4] = X[5]*gravity; ra[%d][5] = X[8]*gravity;" % (j, j, j, j))
+        else:
+            self.gen_add_code_line("grid_xmul(rv[%d], X, rv[%d]); rv[%d][%d] += qd_r;" % (j, p, j, s))
+            self.gen_add_code_line("grid_xmul(ra[%d], X, ra[%d]); grid_mxS_peq<T,%d>(ra[%d], rv[%d], qd_r);" % (j, p, s, j, j))
+        self.gen_add_code_line("T Iv[6]; grid_imul_%d(Iv, rv[%d]); grid_imul_%d(rf[%d], ra[%d]); grid_fxv_peq(rf[%d], rv[%d], Iv); grid_pin6(rf[%d]);" % (j, j, j, j, j, j, j, j))
+        self.gen_add_end_control_flow()
+
+    def rnea_bwd_all():
+        self.gen_add_code_line("// RNEA backward sweep (children before parents): c = S^T f + damping*qd, f_parent += X^T f")
+        for j in range(n - 1, -1, -1):
+            s, p = m.S_index[j], m.parent[j]
+            damp = m.damping[j]
+            self._cur_joint = j
+            self.gen_add_code_line("c[%d] = rf[%d][%d]%s; grid_pin(c[%d]);" % (j, j, s, (" + static_cast<T>(" + repr(float(damp)) + ")*s_qd[%d]" % j) if damp != 0.0 else "", j))
+            if p != -1:
+                self.gen_add_code_line("{ T X[18]; grid_load_X(X, &s_X[GRID_X_STRIDE*%d]); grid_xtmul_peq(rf[%d], X, rf[%d]); grid_pin6(rf[%d]); }" % (j, p, j, p))
+        self._cur_joint = None
+
+    self.gen_direct_minv_inner(use_thread_group, body_only=True, bwd_hook=rnea_fwd_step, fwd_hook=rnea_bwd_all)
+    self.gen_add_sync(use_thread_group)
     self.gen_forward_dynamics_finish_function_call(use_thread_group)
     self.gen_add_end_function()
 

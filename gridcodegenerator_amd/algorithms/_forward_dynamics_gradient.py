@@ -28,10 +28,25 @@ def gen_forward_dynamics_gradient_kernel_max_temp_mem_size(self):
 def gen_forward_dynamics_gradient_inner_python(self, use_thread_group=False, use_qdd_Minv_input=False, s_df_du_name="s_df_du"):
     """Emits the body shared by the device functions and the kernels; expects s_q/s_qd/(s_u)/s_qdd/s_Minv/s_X/s_U/s_T to be bound."""
     n = self.model.n
+    import os
+    stop = int(os.environ.get("GRID_DEBUG_STOP", "0"))  # timing ablation only (results are wrong when set): 1 = X update, 2 = +Minv, 3 = +RNEA/qdd, 4 = +gradient walk
+    if stop == 1:
+        self.gen_add_code_line("if (lane < %d) { %s[lane] = s_X[GRID_X_STRIDE*lane]; }" % (n, s_df_du_name))
+        return
+    if stop == 2:
+        self.gen_direct_minv_inner_function_call(use_thread_group)
+        self.gen_add_code_line("if (lane < %d) { %s[lane] = s_Minv[lane]; }" % (n, s_df_du_name))
+        return
     if not use_qdd_Minv_input:
         self.gen_forward_dynamics_inner_function_call(use_thread_group)  # Minv, c, qdd (v is recomputed below inside the fused gradient walk)
+    if stop == 3:
+        self.gen_add_code_line("if (lane < %d) { %s[lane] = s_qdd[lane]; }" % (n, s_df_du_name))
+        return
     self.gen_add_code_line(self.gen_gradient_outputs_decl())
     self.gen_inverse_dynamics_gradient_inner_function_call(use_thread_group)
+    if stop == 4:
+        self.gen_dc_du_to_lds(s_df_du_name)
+        return
     self.gen_add_code_line("// finally df/du = -Minv*dc/du for the column(s) this lane owns (Minv is read wave-uniformly from LDS)")
     self.gen_dc_du_to_lds(s_df_du_name, minv_name="s_Minv")
 

@@ -118,13 +118,19 @@ def gen_kernel_load_inputs(self, name, stride, amount, use_thread_group=False, n
     """global -> this solve's LDS slice.  Consecutive lanes read consecutive floats and consecutive lane groups read
     consecutive solves, so a wave's loads cover one contiguous span of the AoS input (SURVEY.md 8(a) a1 layout)."""
     self.gen_add_code_line("// load this solve's inputs to LDS (coalesced across the lane groups of the wave)")
+    G = self.lanes_per_solve
     for (nm, st, am) in ((name, stride, amount), (name2, stride2, amount2)):
         if nm is None:
             continue
+        trips = (int(am) + G - 1) // G
         self.gen_add_code_line("const T *d_" + nm + "_k = &d_" + nm + "[kc*" + str(st) + "];")
-        self.gen_add_parallel_loop("ind", str(am), use_thread_group)
-        self.gen_add_code_line("s_" + nm + "[ind] = d_" + nm + "_k[ind];")
-        self.gen_add_end_control_flow()
+        self.gen_add_code_line("{ // all global loads are issued before the first LDS write (one memory latency instead of %d)" % trips)
+        self.gen_add_code_line("  T r_in[%d];" % trips)
+        self.gen_add_code_line("  #pragma unroll")
+        self.gen_add_code_line("  for (int it = 0; it < %d; it++) { const int ind = lane + it*GRID_LANES_PER_SOLVE; r_in[it] = (ind < %s) ? d_%s_k[ind] : static_cast<T>(0); }" % (trips, str(am), nm))
+        self.gen_add_code_line("  #pragma unroll")
+        self.gen_add_code_line("  for (int it = 0; it < %d; it++) { const int ind = lane + it*GRID_LANES_PER_SOLVE; if (ind < %s) { s_%s[ind] = r_in[it]; } }" % (trips, str(am), nm))
+        self.gen_add_code_line("}")
     if name3 is not None:
         n = symmetrize3
         self.gen_add_code_line("const T *d_" + name3 + "_k = &d_" + name3 + "[kc*" + str(stride3) + "];")
@@ -166,7 +172,7 @@ def gen_kernel_save_result(self, store_to_name, stride, amount, use_thread_group
                              "const T *src = " + load_from_name + " - (grp - gw0)*" + str(amount) + ";",
                              "T *dst = &d_" + store_to_name + "[(k - grp + gw0)*" + str(amount) + "];",
                              "const int wl = tid & 63;",
-                             "for (int e = 4*wl; e + 3 < total; e += 256) { T tmp[4]; __builtin_memcpy(tmp, __builtin_assume_aligned(src + e, 4*sizeof(T) < 16 ? 4*sizeof(T) : 16), 4*sizeof(T)); __builtin_memcpy(dst + e, tmp, 4*sizeof(T)); }",
+                             "for (int e = 4*wl; e + 3 < total; e += 256) { T tmp[4]; __builtin_memcpy(tmp, __builtin_assume_aligned(src + e, 4*sizeof(T) < 16 ? 4*sizeof(T) : 16), 4*sizeof(T)); grid_store4(dst + e, tmp); }",
                              "{ const int e = (total & ~3) + wl; if (wl < 3 && e < total) { dst[e] = src[e]; } }"])
     self.gen_add_end_control_flow()
     self.gen_add_sync(use_thread_group)

@@ -38,6 +38,10 @@ __device__ __forceinline__ void grid_pin6(T (&v)[6]) {
     for (int r = 0; r < 6; r++) { asm volatile("" : "+v"(v[r])); }
 }
 
+// 16-byte global store of a finished output record chunk (the address is only 4-byte aligned in general; gfx950 handles that)
+template <typename T>
+__device__ __forceinline__ void grid_store4(T *dst, const T (&v)[4]) { @@STORE4@@ }
+
 // reciprocal: one v_rcp_f32 (1 ulp) instead of the ~10-instruction IEEE division sequence
 __device__ __forceinline__ float grid_rcp(const float x) { return __frcp_rn(x); }
 __device__ __forceinline__ double grid_rcp(const double x) { return 1.0/x; }
@@ -142,7 +146,12 @@ def gen_spatial_algebra_helpers(self):
     Link inertias are rigid-body inertias (10 parameters: Ibar symmetric 3x3, h = m*c, m), so
     I*[w;v] = [Ibar w + h x v ; m v - h x w] costs 24 FMAs with 10 constants instead of a dense 36/36;
     a general symmetric 6x6 (e.g. a caller-supplied composite inertia) falls back to the dense form."""
-    for line in _SPATIAL_LIBRARY.strip("\n").split("\n"):
+    import os
+    store4 = "__builtin_memcpy(dst, v, 4*sizeof(T));"
+    if os.environ.get("GRID_NT_STORE", "0") == "1":  # tuning knob: streaming (non-temporal) output stores
+        store4 = ("typedef T vec4_t __attribute__((ext_vector_type(4), aligned(4))); vec4_t x = {v[0], v[1], v[2], v[3]}; "
+                  "__builtin_nontemporal_store(x, reinterpret_cast<vec4_t *>(dst));")
+    for line in _SPATIAL_LIBRARY.replace("@@STORE4@@", store4).strip("\n").split("\n"):
         self.gen_add_code_line(line)
     self.gen_add_code_line("")
     m = self.model
