@@ -18,27 +18,30 @@ from .robot import DuckRobot
 class GRiDCodeGenerator:
     # emission primitives, device math, model constants (free functions taking self, like the reference's layout)
     from .helpers import gen_add_code_line, gen_add_code_lines, gen_add_end_control_flow, gen_add_end_function, \
-        gen_add_func_doc, gen_add_serial_ops, gen_add_parallel_loop, gen_add_sync, gen_var_in_list, gen_var_not_in_list, \
+        gen_add_func_doc, gen_add_serial_ops, gen_add_parallel_loop, gen_add_sync, gen_var_in_list, gen_var_not_in_list, gen_add_multi_threaded_select, \
         gen_lane_mask_test, gen_kernel_prologue, gen_kernel_load_inputs, gen_kernel_save_result, gen_kernel_save_result_single_timing, \
         gen_spatial_algebra_helpers, gen_mx_func_call_for_cpp, \
         gen_lds_layout, gen_model_constant_table, gen_get_XI_size, gen_topology_helpers_size, gen_init_XImats, gen_init_topology_helpers, gen_init_robotModel, \
-        gen_load_update_XImats_helpers_function_call, gen_load_update_XImats_helpers, gen_topology_sparsity_helpers_python
+        gen_load_update_XImats_helpers_function_call, gen_load_update_XImats_helpers, gen_topology_sparsity_helpers_python, gen_topology_helpers_pointers_for_cpp
 
     # algorithms on the forward-dynamics-gradient path
     from .algorithms import gen_tree_traversal, \
         gen_inverse_dynamics_inner_temp_mem_size, gen_inverse_dynamics_inner_function_call, gen_inverse_dynamics_inner, \
-        gen_inverse_dynamics_kernel, gen_inverse_dynamics_host, gen_inverse_dynamics, \
+        gen_inverse_dynamics_device, gen_inverse_dynamics_kernel, gen_inverse_dynamics_host, gen_inverse_dynamics, \
         gen_direct_minv_inner_temp_mem_size, gen_direct_minv_inner_function_call, gen_direct_minv_inner, gen_direct_minv_inner_header, gen_direct_minv_inner_body, \
-        gen_direct_minv_kernel, gen_direct_minv_host, gen_direct_minv, \
+        gen_direct_minv_device, gen_direct_minv_kernel, gen_direct_minv_host, gen_direct_minv, \
         gen_forward_dynamics_inner_temp_mem_size, gen_forward_dynamics_finish_function_call, gen_forward_dynamics_finish, \
-        gen_forward_dynamics_inner_function_call, gen_forward_dynamics_inner, gen_forward_dynamics_kernel, \
+        gen_forward_dynamics_inner_function_call, gen_forward_dynamics_inner, gen_forward_dynamics_device, gen_forward_dynamics_kernel, \
         gen_forward_dynamics_host, gen_forward_dynamics, \
         gen_inverse_dynamics_gradient_inner_temp_mem_size, gen_inverse_dynamics_gradient_kernel_max_temp_mem_size, \
         gen_inverse_dynamics_gradient_inner_function_call, gen_inverse_dynamics_gradient_inner, gen_dc_du_to_lds, gen_gradient_slots, gen_gradient_outputs_decl, \
-        gen_inverse_dynamics_gradient_kernel, gen_inverse_dynamics_gradient_host, gen_inverse_dynamics_gradient, \
+        gen_inverse_dynamics_gradient_device, gen_inverse_dynamics_gradient_kernel, gen_inverse_dynamics_gradient_host, gen_inverse_dynamics_gradient, \
         gen_forward_dynamics_gradient_inner_temp_mem_size, gen_forward_dynamics_gradient_kernel_max_temp_mem_size, \
         gen_forward_dynamics_gradient_inner_python, gen_forward_dynamics_gradient_device, gen_forward_dynamics_gradient_kernel, \
         gen_forward_dynamics_gradient_host, gen_forward_dynamics_gradient, gen_forward_dynamics_gradient_device_function_call
+
+    # NumPy debug helpers with the reference's names and signatures (reference GRiDCodeGenerator.py:50-51, README "Additional Features")
+    from ._test import test_rnea, test_minv, test_rnea_grad, test_fd_grad
 
     def __init__(self, robotObj, DEBUG_MODE=False, NEED_PRINT_MAT=False, USE_DYNAMIC_SHARED_MEM=True, FILE_NAMESPACE="grid", COLS_PER_LANE=None):
         self.robot = robotObj
@@ -108,7 +111,7 @@ class GRiDCodeGenerator:
         G = self.lanes_per_solve
         max_groups = self.suggested_threads // G
         count = max_groups * (lds["TOTAL"] + lds["OUT_PER_SOLVE"])
-        dva_cols, df_cols = self.gen_topology_sparsity_helpers_python()
+        _sp = self.gen_topology_sparsity_helpers_python(); dva_cols, df_cols = _sp[0], _sp[3]
         self.gen_add_code_lines(["const int NUM_JOINTS = " + str(n) + ";",
                                  "const int NUM_VEL = " + str(n) + ";",
                                  "const int NUM_EES = " + str(sum(1 for c in self.model.children if not c)) + ";",

@@ -167,6 +167,21 @@ def gen_direct_minv_inner_body(self, use_thread_group=False, bwd_hook=None, fwd_
     self.gen_add_end_control_flow()
 
 
+def gen_direct_minv_device(self, use_thread_group=False):
+    self.gen_add_func_doc("Compute the inverse of the mass matrix: X(q) update + direct_minv_inner (lane-group cooperative)",
+                          ["all lanes of the solve's lane group must call it; s_Minv (dense, symmetric) is visible to the group on return"],
+                          ["s_Minv is the n x n output in LDS", "s_q is the vector of joint positions in LDS",
+                           "s_work is this solve's LDS workspace of GRID_LDS_PER_SOLVE elements", "d_robotModel is the pointer to the initialized model specific helpers on the GPU",
+                           "lane is the caller's lane index inside the solve's lane group"], None)
+    self.gen_add_code_line("template <typename T>")
+    self.gen_add_code_line("__device__ __forceinline__")
+    self.gen_add_code_line("void direct_minv_device(T *s_Minv, const T *s_q, T *s_work, const robotModel<T> *d_robotModel, const int lane) {", True)
+    self.gen_add_code_line("T *s_X = &s_work[GRID_OFF_X]; T *s_U = &s_work[GRID_OFF_U]; T *s_T = &s_work[GRID_OFF_T];")
+    self.gen_load_update_XImats_helpers_function_call(use_thread_group)
+    self.gen_direct_minv_inner_function_call(use_thread_group)
+    self.gen_add_end_function()
+
+
 def gen_direct_minv_kernel(self, use_thread_group=False, single_call_timing=False):
     n = self.model.n
     func_params = ["d_Minv is the output: upper triangle of M^-1, column-major (d_Minv[k*n*n + col*n + row], entries below the diagonal are 0)",
@@ -182,7 +197,7 @@ def gen_direct_minv_kernel(self, use_thread_group=False, single_call_timing=Fals
     self.gen_add_code_line(func_def, True)
     self.gen_kernel_prologue("GRID_LDS_PER_SOLVE")
     self.gen_add_code_lines(["T *s_q = &s_mem[GRID_OFF_IN];",
-                             "T *s_X = &s_mem[GRID_OFF_X]; T *s_U = &s_mem[GRID_OFF_U]; T *s_T = &s_mem[GRID_OFF_T]; T *s_Minv = &s_mem[GRID_OFF_MINV]; T *s_out = &s_out_all[grp*%d];" % (n * n)])
+                             "T *s_Minv = &s_mem[GRID_OFF_MINV]; T *s_out = &s_out_all[grp*%d];" % (n * n)])
     if single_call_timing:
         self.gen_add_code_line("const int k = 0; const int kc = 0; const bool valid = (blockIdx.x + blockIdx.y == 0) && (grp == 0); const int lane = lane_id; const int NUM_TIMESTEPS_OUT = 1;")
         self.gen_add_code_line("if (!valid) {return;}")
@@ -192,8 +207,7 @@ def gen_direct_minv_kernel(self, use_thread_group=False, single_call_timing=Fals
     if single_call_timing:
         self.gen_add_code_line("for (int rep = 0; rep < NUM_TIMESTEPS; rep++){", True)
     self.gen_add_code_line("// compute")
-    self.gen_load_update_XImats_helpers_function_call(use_thread_group)
-    self.gen_direct_minv_inner_function_call(use_thread_group)
+    self.gen_add_code_line("direct_minv_device<T>(s_Minv, s_q, s_mem, d_robotModel, lane);")
     if single_call_timing:
         self.gen_add_end_control_flow()
     self.gen_add_code_line("// upper triangle only in the output record")
@@ -250,6 +264,7 @@ def gen_direct_minv_host(self, mode=0):
 
 def gen_direct_minv(self, use_thread_group=False):
     self.gen_direct_minv_inner(use_thread_group)
+    self.gen_direct_minv_device(use_thread_group)
     self.gen_direct_minv_kernel(use_thread_group, True)
     self.gen_direct_minv_kernel(use_thread_group, False)
     for mode in (0, 1, 2):

@@ -97,6 +97,22 @@ def gen_forward_dynamics_inner(self, use_thread_group=False):
     self.gen_add_end_function()
 
 
+def gen_forward_dynamics_device(self, use_thread_group=False):
+    self.gen_add_func_doc("Computes forward dynamics: X(q) update + forward_dynamics_inner (lane-group cooperative)",
+                          ["all lanes of the solve's lane group must call it; s_qdd is visible to the group on return"],
+                          ["s_qdd is the output vector of joint accelerations in LDS", "s_q is the vector of joint positions", "s_qd is the vector of joint velocities",
+                           "s_u is the vector of joint input torques", "s_work is this solve's LDS workspace of GRID_LDS_PER_SOLVE elements",
+                           "d_robotModel is the pointer to the initialized model specific helpers on the GPU", "gravity is the gravity constant",
+                           "lane is the caller's lane index inside the solve's lane group"], None)
+    self.gen_add_code_line("template <typename T>")
+    self.gen_add_code_line("__device__ __forceinline__")
+    self.gen_add_code_line("void forward_dynamics_device(T *s_qdd, const T *s_q, const T *s_qd, const T *s_u, T *s_work, const robotModel<T> *d_robotModel, const T gravity, const int lane) {", True)
+    self.gen_add_code_line("T *s_X = &s_work[GRID_OFF_X]; T *s_U = &s_work[GRID_OFF_U]; T *s_T = &s_work[GRID_OFF_T]; T *s_Minv = &s_work[GRID_OFF_MINV];")
+    self.gen_load_update_XImats_helpers_function_call(use_thread_group)
+    self.gen_forward_dynamics_inner_function_call(use_thread_group)
+    self.gen_add_end_function()
+
+
 def gen_forward_dynamics_kernel(self, use_thread_group=False, single_call_timing=False):
     n = self.model.n
     func_params = ["d_qdd is the vector of joint accelerations", "d_q_qd_u is the vector of joint positions, velocities, and input torques",
@@ -113,7 +129,7 @@ def gen_forward_dynamics_kernel(self, use_thread_group=False, single_call_timing
     self.gen_add_code_line(func_def, True)
     self.gen_kernel_prologue("GRID_LDS_PER_SOLVE")
     self.gen_add_code_lines(["T *s_q_qd_u = &s_mem[GRID_OFF_IN]; T *s_q = s_q_qd_u; T *s_qd = &s_q_qd_u[%d]; T *s_u = &s_q_qd_u[%d];" % (n, 2 * n),
-                             "T *s_X = &s_mem[GRID_OFF_X]; T *s_U = &s_mem[GRID_OFF_U]; T *s_T = &s_mem[GRID_OFF_T]; T *s_Minv = &s_mem[GRID_OFF_MINV]; T *s_qdd = &s_out_all[grp*%d];" % n])
+                             "T *s_qdd = &s_out_all[grp*%d];" % n])
     if single_call_timing:
         self.gen_add_code_line("const int k = 0; const int kc = 0; const bool valid = (blockIdx.x + blockIdx.y == 0) && (grp == 0); const int lane = lane_id; const int NUM_TIMESTEPS_OUT = 1;")
         self.gen_add_code_line("if (!valid) {return;}")
@@ -123,8 +139,7 @@ def gen_forward_dynamics_kernel(self, use_thread_group=False, single_call_timing
     if single_call_timing:
         self.gen_add_code_line("for (int rep = 0; rep < NUM_TIMESTEPS; rep++){", True)
     self.gen_add_code_line("// compute")
-    self.gen_load_update_XImats_helpers_function_call(use_thread_group)
-    self.gen_forward_dynamics_inner_function_call(use_thread_group)
+    self.gen_add_code_line("forward_dynamics_device<T>(s_qdd, s_q, s_qd, s_u, s_mem, d_robotModel, gravity, lane);")
     if single_call_timing:
         self.gen_add_end_control_flow()
     if single_call_timing:
@@ -176,6 +191,7 @@ def gen_forward_dynamics_host(self, mode=0):
 def gen_forward_dynamics(self, use_thread_group=False):
     self.gen_forward_dynamics_finish(use_thread_group)
     self.gen_forward_dynamics_inner(use_thread_group)
+    self.gen_forward_dynamics_device(use_thread_group)
     self.gen_forward_dynamics_kernel(use_thread_group, True)
     self.gen_forward_dynamics_kernel(use_thread_group, False)
     for mode in (0, 1, 2):

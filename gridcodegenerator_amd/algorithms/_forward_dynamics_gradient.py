@@ -112,8 +112,7 @@ def gen_forward_dynamics_gradient_kernel(self, use_thread_group=False, use_qdd_M
         self.gen_add_code_line("T *s_q_qd = &s_mem[GRID_OFF_IN]; T *s_q = s_q_qd; T *s_qd = &s_q_qd[%d]; T *s_qdd = &s_mem[GRID_OFF_QDD];" % n)
     else:
         self.gen_add_code_line("T *s_q_qd_u = &s_mem[GRID_OFF_IN]; T *s_q = s_q_qd_u; T *s_qd = &s_q_qd_u[%d]; T *s_u = &s_q_qd_u[%d]; T *s_qdd = &s_mem[GRID_OFF_QDD];" % (n, 2 * n))
-    self.gen_add_code_line("T *s_X = &s_mem[GRID_OFF_X]; T *s_U = &s_mem[GRID_OFF_U]; T *s_T = &s_mem[GRID_OFF_T]; T *s_Minv = &s_mem[GRID_OFF_MINV]; T *s_F = &s_mem[GRID_OFF_F]; T *s_J = &s_mem[GRID_OFF_J]; T *s_df_du = &s_out_all[grp*%d];" % (2 * n * n))
-    self.gen_add_code_line("(void)s_U; (void)s_T;")
+    self.gen_add_code_line("T *s_Minv = &s_mem[GRID_OFF_MINV]; T *s_df_du = &s_out_all[grp*%d]; (void)s_Minv; (void)s_qdd;" % (2 * n * n))
     if single_call_timing:
         self.gen_add_code_line("const int k = 0; const int kc = 0; const bool valid = (blockIdx.x + blockIdx.y == 0) && (grp == 0); const int lane = lane_id; const int NUM_TIMESTEPS_OUT = 1;")
         self.gen_add_code_line("if (!valid) {return;}")
@@ -127,8 +126,7 @@ def gen_forward_dynamics_gradient_kernel(self, use_thread_group=False, use_qdd_M
         self.gen_add_code_line("// compute with NUM_TIMESTEPS as NUM_REPS for timing")
         self.gen_add_code_line("for (int rep = 0; rep < NUM_TIMESTEPS; rep++){", True)
     self.gen_add_code_line("// compute")
-    self.gen_load_update_XImats_helpers_function_call(use_thread_group)
-    self.gen_forward_dynamics_gradient_inner_python(use_thread_group, use_qdd_Minv_input)
+    self.gen_forward_dynamics_gradient_device_function_call(compute_Minv=use_qdd_Minv_input)
     if single_call_timing:
         self.gen_add_end_control_flow()
     if single_call_timing:
@@ -184,9 +182,9 @@ def gen_forward_dynamics_gradient_host(self, mode=0):
 
 def gen_forward_dynamics_gradient_device_function_call(self, compute_Minv=False):
     if compute_Minv:
-        self.gen_add_code_line("forward_dynamics_gradient_device<T>(s_df_du, s_q, s_qd, s_qdd, s_Minv, s_work, d_robotModel, gravity, lane);")
+        self.gen_add_code_line("forward_dynamics_gradient_device<T>(s_df_du, s_q, s_qd, s_qdd, s_Minv, s_mem, d_robotModel, gravity, lane);")
     else:
-        self.gen_add_code_line("forward_dynamics_gradient_device<T>(s_df_du, s_q, s_qd, s_u, s_work, d_robotModel, gravity, lane);")
+        self.gen_add_code_line("forward_dynamics_gradient_device<T>(s_df_du, s_q, s_qd, s_u, s_mem, d_robotModel, gravity, lane);")
 
 
 def gen_forward_dynamics_gradient(self, use_thread_group=False):

@@ -90,6 +90,31 @@ def gen_inverse_dynamics_inner(self, use_thread_group=False, use_qdd_input=False
     self.gen_add_end_function()
 
 
+def gen_inverse_dynamics_device(self, use_thread_group=False, use_qdd_input=False):
+    n = self.model.n
+    params = ["s_c is the output vector of torques in LDS", "s_q is the vector of joint positions in LDS", "s_qd is the vector of joint velocities in LDS"]
+    if use_qdd_input:
+        params.append("s_qdd is the vector of joint accelerations in LDS")
+    params += ["s_work is this solve's LDS workspace of GRID_LDS_PER_SOLVE elements", "d_robotModel is the pointer to the initialized model specific helpers on the GPU",
+               "gravity is the gravity constant", "lane is the caller's lane index inside the solve's lane group"]
+    self.gen_add_func_doc("Compute the RNEA (Recursive Newton-Euler Algorithm): X(q) update + inverse_dynamics_inner (lane-group cooperative)",
+                          ["all lanes of the solve's lane group must call it; s_c is visible to the group on return"], params, None)
+    self.gen_add_code_line("template <typename T>")
+    self.gen_add_code_line("__device__ __forceinline__")
+    self.gen_add_code_line("void inverse_dynamics_device(T *s_c, const T *s_q, const T *s_qd, " + ("const T *s_qdd, " if use_qdd_input else "") +
+                           "T *s_work, const robotModel<T> *d_robotModel, const T gravity, const int lane) {", True)
+    self.gen_add_code_line("T *s_X = &s_work[GRID_OFF_X];")
+    self.gen_load_update_XImats_helpers_function_call(use_thread_group)
+    self.gen_add_code_line("T c[%d];" % n)
+    self.gen_inverse_dynamics_inner_function_call(use_thread_group, True, use_qdd_input)
+    self.gen_add_code_line("if (lane == 0) {", True)
+    self.gen_add_code_line("#pragma unroll")
+    self.gen_add_code_line("for (int i = 0; i < %d; i++) { s_c[i] = c[i]; }" % n)
+    self.gen_add_end_control_flow()
+    self.gen_add_sync(use_thread_group)
+    self.gen_add_end_function()
+
+
 def gen_inverse_dynamics_kernel(self, use_thread_group=False, use_qdd_input=False, single_call_timing=False):
     n = self.model.n
     func_params = ["d_c is the vector of output torques", "d_q_dq is the vector of joint positions and velocities",
@@ -110,7 +135,7 @@ def gen_inverse_dynamics_kernel(self, use_thread_group=False, use_qdd_input=Fals
     self.gen_add_code_line(func_def, True)
     self.gen_kernel_prologue("GRID_LDS_PER_SOLVE")
     self.gen_add_code_lines(["T *s_q_qd = &s_mem[GRID_OFF_IN]; T *s_q = s_q_qd; T *s_qd = &s_q_qd[%d]; T *s_qdd = &s_q_qd[%d];" % (n, 2 * n),
-                             "T *s_X = &s_mem[GRID_OFF_X]; T *s_c = &s_out_all[grp*%d];" % n + ""])
+                             "T *s_c = &s_out_all[grp*%d];" % n])
     if single_call_timing:
         self.gen_add_code_line("const int k = 0; const int kc = 0; const bool valid = (blockIdx.x + blockIdx.y == 0) && (grp == 0); const int lane = lane_id; const int NUM_TIMESTEPS_OUT = 1;")
         self.gen_add_code_line("if (!valid) {return;}")
@@ -123,13 +148,7 @@ def gen_inverse_dynamics_kernel(self, use_thread_group=False, use_qdd_input=Fals
     if single_call_timing:
         self.gen_add_code_line("for (int rep = 0; rep < NUM_TIMESTEPS; rep++){", True)
     self.gen_add_code_line("// compute")
-    self.gen_load_update_XImats_helpers_function_call(use_thread_group)
-    self.gen_add_code_line("T c[%d];" % n)
-    self.gen_inverse_dynamics_inner_function_call(use_thread_group, True, use_qdd_input)
-    self.gen_add_code_line("if (lane == 0) {", True)
-    self.gen_add_code_line("#pragma unroll")
-    self.gen_add_code_line("for (int i = 0; i < %d; i++) { s_c[i] = c[i]; }" % n)
-    self.gen_add_end_control_flow()
+    self.gen_add_code_line("inverse_dynamics_device<T>(s_c, s_q, s_qd, " + ("s_qdd, " if use_qdd_input else "") + "s_mem, d_robotModel, gravity, lane);")
     if single_call_timing:
         self.gen_add_end_control_flow()
     if single_call_timing:
@@ -186,6 +205,9 @@ def gen_inverse_dynamics(self, use_thread_group=False):
     # inner (register) functions, both variants
     self.gen_inverse_dynamics_inner(use_thread_group, use_qdd_input=False)
     self.gen_inverse_dynamics_inner(use_thread_group, use_qdd_input=True)
+    # device wrappers
+    self.gen_inverse_dynamics_device(use_thread_group, use_qdd_input=False)
+    self.gen_inverse_dynamics_device(use_thread_group, use_qdd_input=True)
     # kernels
     for use_qdd in (True, False):
         for timing in (True, False):

@@ -233,6 +233,32 @@ def gen_dc_du_to_lds(self, dst="s_dc_du", minv_name=None):
         self.gen_add_end_control_flow()
 
 
+def gen_inverse_dynamics_gradient_device(self, use_thread_group=False, use_qdd_input=False):
+    n = self.model.n
+    params = ["s_dc_du is the output in LDS, 2*NUM_JOINTS*NUM_JOINTS values laid out [col*n + row], col in [0,2n) = [d/dq | d/dqd]",
+              "s_q is the vector of joint positions in LDS", "s_qd is the vector of joint velocities in LDS"]
+    if use_qdd_input:
+        params.append("s_qdd is the vector of joint accelerations in LDS")
+    params += ["s_work is this solve's LDS workspace of GRID_LDS_PER_SOLVE elements", "d_robotModel is the pointer to the initialized model specific helpers on the GPU",
+               "gravity is the gravity constant", "lane is the caller's lane index inside the solve's lane group"]
+    self.gen_add_func_doc("Computes the gradient of inverse dynamics: X(q) update + inverse_dynamics_gradient_inner (lane-group cooperative)",
+                          ["all lanes of the solve's lane group must call it; s_dc_du is visible to the group on return"], params, None)
+    self.gen_add_code_line("template <typename T>")
+    self.gen_add_code_line("__device__ __forceinline__")
+    self.gen_add_code_line("void inverse_dynamics_gradient_device(T *s_dc_du, const T *s_q, const T *s_qd, " + ("const T *s_qdd, " if use_qdd_input else "") +
+                           "T *s_work, const robotModel<T> *d_robotModel, const T gravity, const int lane) {", True)
+    self.gen_add_code_line("T *s_X = &s_work[GRID_OFF_X]; T *s_F = &s_work[GRID_OFF_F]; T *s_J = &s_work[GRID_OFF_J];")
+    if not use_qdd_input:
+        self.gen_add_code_line("T *s_qdd = &s_work[GRID_OFF_QDD];")
+        self.gen_add_code_line("if (lane < %d) { s_qdd[lane] = static_cast<T>(0); }" % n)
+    self.gen_load_update_XImats_helpers_function_call(use_thread_group)
+    self.gen_add_code_line(self.gen_gradient_outputs_decl())
+    self.gen_inverse_dynamics_gradient_inner_function_call(use_thread_group)
+    self.gen_dc_du_to_lds("s_dc_du")
+    self.gen_add_sync(use_thread_group)
+    self.gen_add_end_function()
+
+
 def gen_inverse_dynamics_gradient_kernel(self, use_thread_group=False, use_qdd_input=False, single_call_timing=False):
     n = self.model.n
     func_params = ["d_dc_du is a pointer to memory for the final result of size 2*NUM_JOINTS*NUM_JOINTS = " + str(2 * n * n),
@@ -253,7 +279,7 @@ def gen_inverse_dynamics_gradient_kernel(self, use_thread_group=False, use_qdd_i
     self.gen_add_code_line(func_def, True)
     self.gen_kernel_prologue("GRID_LDS_PER_SOLVE")
     self.gen_add_code_lines(["T *s_q_qd = &s_mem[GRID_OFF_IN]; T *s_q = s_q_qd; T *s_qd = &s_q_qd[%d]; T *s_qdd = &s_q_qd[%d];" % (n, 2 * n),
-                             "T *s_X = &s_mem[GRID_OFF_X]; T *s_F = &s_mem[GRID_OFF_F]; T *s_J = &s_mem[GRID_OFF_J]; T *s_dc_du = &s_out_all[grp*%d];" % (2 * n * n)])
+                             "T *s_dc_du = &s_out_all[grp*%d];" % (2 * n * n)])
     if single_call_timing:
         self.gen_add_code_line("const int k = 0; const int kc = 0; const bool valid = (blockIdx.x + blockIdx.y == 0) && (grp == 0); const int lane = lane_id; const int NUM_TIMESTEPS_OUT = 1;")
         self.gen_add_code_line("if (!valid) {return;}")
@@ -263,14 +289,10 @@ def gen_inverse_dynamics_gradient_kernel(self, use_thread_group=False, use_qdd_i
         self.gen_kernel_load_inputs("q_qd", "stride_q_qd", 2 * n, use_thread_group, "qdd", n, n)
     else:
         self.gen_kernel_load_inputs("q_qd", "stride_q_qd", 2 * n, use_thread_group)
-        self.gen_add_code_line("if (lane < %d) { s_qdd[lane] = static_cast<T>(0); }" % n)
     if single_call_timing:
         self.gen_add_code_line("for (int rep = 0; rep < NUM_TIMESTEPS; rep++){", True)
     self.gen_add_code_line("// compute")
-    self.gen_load_update_XImats_helpers_function_call(use_thread_group)
-    self.gen_add_code_line(self.gen_gradient_outputs_decl())
-    self.gen_inverse_dynamics_gradient_inner_function_call(use_thread_group)
-    self.gen_dc_du_to_lds("s_dc_du")
+    self.gen_add_code_line("inverse_dynamics_gradient_device<T>(s_dc_du, s_q, s_qd, " + ("s_qdd, " if use_qdd_input else "") + "s_mem, d_robotModel, gravity, lane);")
     if single_call_timing:
         self.gen_add_end_control_flow()
     if single_call_timing:
@@ -325,6 +347,8 @@ def gen_inverse_dynamics_gradient_host(self, mode=0):
 
 def gen_inverse_dynamics_gradient(self, use_thread_group=False):
     self.gen_inverse_dynamics_gradient_inner(use_thread_group)
+    self.gen_inverse_dynamics_gradient_device(use_thread_group, use_qdd_input=False)
+    self.gen_inverse_dynamics_gradient_device(use_thread_group, use_qdd_input=True)
     for use_qdd in (True, False):
         for timing in (True, False):
             self.gen_inverse_dynamics_gradient_kernel(use_thread_group, use_qdd, timing)

@@ -90,6 +90,48 @@ def gen_var_not_in_list(self, var_name, option_list):
     return "(" + " && ".join(["(" + var_name + " != " + o + ")" for o in option_list]) + ")"
 
 
+def gen_add_multi_threaded_select(self, loop_counter, comparator, counts, select_tuples, USE_NON_BRANCH_ALWAYS=False):
+    """Selects values by the range `loop_counter` falls into (reference helpers/_code_generation_helpers.py:96-145, same arguments).
+    select_tuples = [(type, name, [value per range])]; ranges are `loop_counter <comparator> counts[i]` tried in order, the last
+    value is the default.  One variable (or USE_NON_BRANCH_ALWAYS) gives a branch-free sum of predicated terms, otherwise an
+    if / else-if chain - on wave64 hardware both compile to v_cndmask selects."""
+    decls = []
+    for (dtype, dvar, _) in select_tuples:
+        if dtype is None:
+            decls.append(dvar)
+        elif "|" in dtype:
+            pre, post = dtype.split("|")
+            decls.append(pre + dvar + ")" + post)
+        else:
+            decls.append(dtype + " " + dvar)
+    k = len(counts)
+    conds = []
+    for i in range(k):
+        c = "(" + loop_counter + " " + comparator + " " + counts[i] + ")"
+        if comparator != "==" and i > 0:
+            c = "(" + c + " && !(" + loop_counter + " " + comparator + " " + counts[i - 1] + "))"
+        conds.append(c)
+    if len(select_tuples) > 1 and not USE_NON_BRANCH_ALWAYS:
+        self.gen_add_code_line("// branch to get pointer locations")
+        self.gen_add_code_line("; ".join(decls) + ";")
+        for i in range(k):
+            head = ("if " if i == 0 else "else if ") + conds[i] if i < k - 1 or comparator == "==" else "else"
+            if i == k - 1 and comparator != "==":
+                head = "else"
+            body = " ".join(dvar + " = " + vals[i] + ";" for (_, dvar, vals) in select_tuples)
+            self.gen_add_code_line(head + " { " + body + " }")
+    else:
+        self.gen_add_code_line("// non-branching pointer selector")
+        for t, (_, dvar, vals) in enumerate(select_tuples):
+            terms = []
+            for i in range(k):
+                cond = conds[i]
+                if i == k - 1 and comparator != "==":
+                    cond = "!(" + loop_counter + " " + comparator + " " + counts[k - 2] + ")" if k > 1 else "1"
+                terms.append(cond + " * " + vals[i])
+            self.gen_add_code_line(decls[t] + " = " + " + ".join(terms) + ";")
+
+
 def gen_lane_mask_test(self, ids, var_name="lane"):
     """Compile-time lane-set membership as a 64-bit mask test (used for per-joint-type dispatch)."""
     mask = 0

@@ -195,11 +195,48 @@ def gen_load_update_XImats_helpers(self, use_thread_group=False):
     self.gen_add_end_function()
 
 
-def gen_topology_sparsity_helpers_python(self):
-    """Column bookkeeping the reference needs for its sparsity-compressed layout (helpers/_topology_helpers.py:515-542).
-    With lane j owning columns d/dq_j and d/dq'_j, zeros propagate structurally and no compressed layout is needed;
-    the counts are still reported because SUGGESTED_THREADS-style sizing and DESIGN.md quote them."""
+def gen_topology_sparsity_helpers_python(self, INIT_MODE=False):
+    """Column bookkeeping of the reference's sparsity-compressed derivative layout, same return values as the reference
+    (helpers/_topology_helpers.py:515-542).  Our kernels do not need it (joint-ordered column slots + structural zeros);
+    it is kept as a topology query for code written against the reference's Code Generation API."""
     m = self.model
-    dva_cols = sum(len(a) + 1 for a in m.ancestors)
-    df_cols = sum(len(m.ancestors[j]) + len(m.subtree[j]) for j in range(m.n))
-    return dva_cols, df_cols
+    n = m.n
+    num_anc = [len(a) for a in m.ancestors]
+    num_sub = [len(s_) for s_ in m.subtree]
+    run_anc = [sum(num_anc[:j]) for j in range(n + 1)]
+    run_sub = [sum(num_sub[:j]) for j in range(n)]
+    if INIT_MODE:
+        return [str(x) for x in num_anc], [str(x) for x in num_sub], [str(x) for x in run_anc], [str(x) for x in run_sub]
+    dva_cols_per_partial = sum(num_anc) + n
+    df_cols_per_partial = sum(num_anc) + sum(num_sub)
+    dva_cols_per_jid = [x + 1 for x in num_anc]
+    df_cols_per_jid = [num_anc[j] + num_sub[j] for j in range(n)]
+    running_sum_dva_cols_per_jid = [run_anc[j] + j for j in range(n + 1)]
+    running_sum_df_cols_per_jid = [run_anc[j] + run_sub[j] for j in range(n)]
+    return dva_cols_per_partial, dva_cols_per_jid, running_sum_dva_cols_per_jid, df_cols_per_partial, df_cols_per_jid, running_sum_df_cols_per_jid, list(num_anc)
+
+
+def gen_topology_helpers_pointers_for_cpp(self, inds=None, updated_var_names=None, NO_GRAD_FLAG=True, OFFSET=True):
+    """C++ expressions for the parent id and motion-subspace index of joint `jid` (reference helpers/_topology_helpers.py:592-681).
+    For a single joint the values are literals; otherwise they index the [parent | S_index] table of init_topology_helpers().
+    Only the NO_GRAD form is offered: the compressed-column offsets of the reference layout have no counterpart here."""
+    var = dict(jid_name="jid", s_topology_helpers_name="s_topology_helpers")
+    if updated_var_names is not None:
+        var.update(updated_var_names)
+    m = self.model
+    n = m.n
+    if inds is None:
+        inds = list(range(n))
+    if not NO_GRAD_FLAG:
+        raise NotImplementedError("gradient column offsets belong to the reference's compressed layout; see gen_gradient_slots()")
+    if len(inds) == 1:
+        return str(m.parent[inds[0]]), str(m.S_index[inds[0]])
+    if m.is_serial_chain():
+        parent_ind = "(" + var["jid_name"] + "-1)"
+    else:
+        parent_ind = var["s_topology_helpers_name"] + "[" + var["jid_name"] + "]"
+    if len(set(m.S_index[i] for i in inds)) == 1:
+        S_ind = str(m.S_index[inds[0]])
+    else:
+        S_ind = var["s_topology_helpers_name"] + "[" + str(n) + " + " + var["jid_name"] + "]"
+    return parent_ind, S_ind
