@@ -43,7 +43,7 @@ template <typename T>
 __device__ __forceinline__ void grid_store4(T *dst, const T (&v)[4]) { @@STORE4@@ }
 
 // reciprocal: one v_rcp_f32 (1 ulp) instead of the ~10-instruction IEEE division sequence
-__device__ __forceinline__ float grid_rcp(const float x) { return __frcp_rn(x); }
+__device__ __forceinline__ float grid_rcp(const float x) { return __builtin_amdgcn_rcpf(x); }
 __device__ __forceinline__ double grid_rcp(const double x) { return 1.0/x; }
 
 // X is stored compactly per joint: X[0..8] = E (row-major 3x3, top-left == bottom-right block),

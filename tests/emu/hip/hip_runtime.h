@@ -82,7 +82,7 @@ void launch(dim3 grid, dim3 block, size_t smem_bytes, F &&body) {
 }
 }  // namespace hipemu
 
-inline float __frcp_rn(float x) { return 1.0f / x; }
+#define __builtin_amdgcn_rcpf(x) (1.0f / (x))
 #define __builtin_amdgcn_fence(order, scope) ((void)0)
 #define __builtin_amdgcn_wave_barrier() hipemu::wave_barrier()
 #define hipLaunchKernelGGL(kernel, grid, block, smem, stream, ...) hipemu::launch((grid), (block), (smem), [&]() { kernel(__VA_ARGS__); })
