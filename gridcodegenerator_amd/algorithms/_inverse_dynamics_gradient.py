@@ -207,7 +207,90 @@ def gen_inverse_dynamics_gradient_inner(self, use_thread_group=False):
             self.gen_add_end_control_flow()
             self.gen_add_end_control_flow()
 
-    self.gen_tree_traversal(pre, post)
+    # ---- register-resident variant: for shallow trees the whole derivative walk stays in VGPRs -------------------------------
+    # (every link keeps its f and its live df slots until the walk returns: 6 + 6*slots VGPRs per tree level).  The backward
+    # sweep df_parent += X^T df (oracle _test.py:450-470) then replaces the Jacobian dots, the J/F hand-offs through LDS and all
+    # wave-level syncs of the walk.  Deep trees keep the forward-accumulation form above (O(1) registers per level).
+    def pre_reg(k):
+        s, p = m.S_index[k], m.parent[k]
+        K, P = str(k), str(p)
+        act = [sl for sl in slots if sl["live"][k]]
+        back = [sl for sl in slots if sl["live"][k] or sl["live_w"][k]]  # slots whose df exists at this link (own or from the subtree)
+        decl = ["v_%s[6]" % K, "a_%s[6]" % K, "f_%s[6]" % K]
+        for sl in act:
+            decl += ["dv%s_%s[6]" % (sl["name"], K), "da%s_%s[6]" % (sl["name"], K)]
+        for sl in back:
+            decl.append("df%s_%s[6]" % (sl["name"], K))
+        self.gen_add_code_line("T " + ", ".join(decl) + ";")
+        own = [sl for sl in slots if sl["lo"] <= k < sl["hi"]][0]
+        self.gen_add_code_line("const T selq_%s = (jc_%s == %s && !is_qd) ? %s : %s; const T seld_%s = (jc_%s == %s && is_qd) ? %s : %s;" %
+                               (K, own["name"], K, ONE, ZERO, K, own["name"], K, ONE, ZERO))
+        self.gen_add_code_line("{", True)
+        self.gen_add_code_line("T X[18]; grid_load_X(X, &s_X[GRID_X_STRIDE*" + K + "]);")
+        self.gen_add_code_line("const T qd = s_qd[" + K + "]; const T qdd = s_qdd[" + K + "];")
+        self.gen_add_code_line("T Xa[6], Mxv[6], MxXa[6], Iv[6];")
+        if p == -1:
+            self.gen_add_code_line("grid_zero6(v_%s); v_%s[%d] = qd;" % (K, K, s))
+            self.gen_add_code_line("grid_zero6(Xa); Xa[3] = X[2]*gravity; Xa[4] = X[5]*gravity; Xa[5] = X[8]*gravity;")
+        else:
+            self.gen_add_code_line("grid_xmul(v_%s, X, v_%s); v_%s[%d] += qd;" % (K, P, K, s))
+            self.gen_add_code_line("grid_xmul(Xa, X, a_%s);" % P)
+        self.gen_add_code_line("grid_zero6(Mxv); grid_mxS_peq<T,%d>(Mxv, v_%s, %s);" % (s, K, ONE))
+        self.gen_add_code_line("grid_zero6(MxXa); grid_mxS_peq<T,%d>(MxXa, Xa, %s);" % (s, ONE))
+        self.gen_add_code_line("#pragma unroll")
+        self.gen_add_code_line("for (int r = 0; r < 6; r++) { a_%s[r] = Xa[r] + Mxv[r]*qd; }" % K)
+        self.gen_add_code_line("a_%s[%d] += qdd;" % (K, s))
+        self.gen_add_code_line("grid_imul_%s(Iv, v_%s); grid_imul_%s(f_%s, a_%s); grid_fxv_peq(f_%s, v_%s, Iv); grid_pin6(f_%s);" % (K, K, K, K, K, K, K, K))
+        for sl in act:
+            c = sl["name"]
+            is_own = sl is own
+            if p != -1 and sl["live"][p]:
+                self.gen_add_code_line("grid_xmul(dv%s_%s, X, dv%s_%s); grid_xmul(da%s_%s, X, da%s_%s);" % (c, K, c, P, c, K, c, P))
+                if is_own:
+                    self.gen_add_code_line("#pragma unroll")
+                    self.gen_add_code_line("for (int r = 0; r < 6; r++) { dv%s_%s[r] += selq_%s*Mxv[r]; da%s_%s[r] += selq_%s*MxXa[r] + seld_%s*Mxv[r]; }" % (c, K, K, c, K, K, K))
+                    self.gen_add_code_line("dv%s_%s[%d] += seld_%s;" % (c, K, s, K))
+            else:
+                self.gen_add_code_line("#pragma unroll")
+                self.gen_add_code_line("for (int r = 0; r < 6; r++) { dv%s_%s[r] = selq_%s*Mxv[r]; da%s_%s[r] = selq_%s*MxXa[r] + seld_%s*Mxv[r]; }" % (c, K, K, c, K, K, K))
+                self.gen_add_code_line("dv%s_%s[%d] += seld_%s;" % (c, K, s, K))
+            self.gen_add_code_line("grid_mxS_peq<T,%d>(da%s_%s, dv%s_%s, qd);" % (s, c, K, c, K))
+            self.gen_add_code_line("{ T Idv[6]; grid_imul_%s(df%s_%s, da%s_%s); grid_fxv_peq(df%s_%s, dv%s_%s, Iv); grid_imul_%s(Idv, dv%s_%s); grid_fxv_peq(df%s_%s, v_%s, Idv); grid_pin6(df%s_%s); }" %
+                                   (K, c, K, c, K, c, K, c, K, K, c, K, c, K, K, c, K))
+        for sl in back:
+            if sl not in act:
+                self.gen_add_code_line("grid_zero6(df%s_%s);" % (sl["name"], K))
+        self.gen_add_end_control_flow()
+
+    def post_reg(k):
+        s, p = m.S_index[k], m.parent[k]
+        K, P = str(k), str(p)
+        damp = m.damping[k]
+        own = [sl for sl in slots if sl["lo"] <= k < sl["hi"]][0]
+        back = [sl for sl in slots if sl["live"][k] or sl["live_w"][k]]
+        for sl in back:
+            self.gen_add_code_line("dc_%s[%s] = df%s_%s[%d]; grid_pin(dc_%s[%s]);" % (sl["name"], K, sl["name"], K, s, sl["name"], K))
+        if damp != 0.0:
+            self.gen_add_code_line("dc_%s[%s] += seld_%s*static_cast<T>(%s);" % (own["name"], K, K, repr(float(damp))))
+        if p != -1:
+            self.gen_add_code_line("{", True)
+            self.gen_add_code_line("T X[18]; grid_load_X(X, &s_X[GRID_X_STRIDE*" + K + "]);")
+            self.gen_add_code_line("// column == joint picks up -X^T mxS(S, f_subtree); everything is carried to the parent frame")
+            self.gen_add_code_line("grid_mxS_peq<T,%d>(df%s_%s, f_%s, -selq_%s);" % (s, own["name"], K, K, K))
+            self.gen_add_code_line("grid_xtmul_peq(f_%s, X, f_%s); grid_pin6(f_%s);" % (P, K, P))
+            for sl in back:
+                self.gen_add_code_line("grid_xtmul_peq(df%s_%s, X, df%s_%s); grid_pin6(df%s_%s);" % (sl["name"], P, sl["name"], K, sl["name"], P))
+            self.gen_add_end_control_flow()
+
+    import os
+    depth_max = max(m.depth) + 1
+    mode = os.environ.get("GRID_GRADIENT_WALK", "auto")  # tuning knob: "registers" | "lds" | "auto"
+    use_regs = (mode == "registers") or (mode == "auto" and depth_max * 6 * (1 + len(slots)) <= 132)
+    if use_regs:
+        self.gen_add_code_line("(void)s_F; (void)s_J; // the register-resident walk needs no LDS hand-offs")
+        self.gen_tree_traversal(pre_reg, post_reg)
+    else:
+        self.gen_tree_traversal(pre, post)
     self.gen_add_end_function()
 
 
