@@ -68,6 +68,10 @@ def gen_direct_minv_inner_body(self, use_thread_group=False, bwd_hook=None, fwd_
         self.gen_add_code_line("const bool isIA = (lane >= %d) && (lane < %d);" % (IA0, IA0 + 6))
     self.gen_add_code_line("const T *d_I = &grid_model_constants(static_cast<const T *>(nullptr))[" + str(18 * n) + " + 6*cI]; (void)d_robotModel;")
     self.gen_add_code_line("T Mcol[" + str(n) + "];")
+    keep_U_in_regs = n <= 9  # 7 VGPRs per joint; larger robots park U_i, 1/D_i in LDS for the forward sweep
+    if keep_U_in_regs:
+        self.gen_add_code_line("T Uk[%d][6], Dk[%d]; // U_i and 1/D_i of every joint, kept for the forward sweep" % (n, n))
+        self.gen_add_code_line("(void)s_U;")
     self.gen_add_code_line("//")
     self.gen_add_code_line("// backward sweep (post-order): U, D^-1, Minv row updates, F and IA propagation to the parent")
     self.gen_add_code_line("//")
@@ -80,17 +84,22 @@ def gen_direct_minv_inner_body(self, use_thread_group=False, bwd_hook=None, fwd_
     def post_b(i):
         s, p = m.S_index[i], m.parent[i]
         tbuf = (m.depth[i] & 1) * 40  # the transpose scratch is double buffered by depth parity
-        self.gen_add_code_line("if (lane == %d) {" % (IA0 + s), True)
-        self.gen_add_code_line("#pragma unroll")
-        self.gen_add_code_line("for (int r = 0; r < 6; r++) { s_U[%d + r] = IA_%d[r]; }" % (8 * i, i))
-        self.gen_add_end_control_flow()
-        self.gen_add_sync(use_thread_group)
         self.gen_add_code_line("{", True)
+        self.gen_add_code_line("// U = IA[:, S] lives in the lane that owns that column: broadcast it inside the lane group (no LDS hand-off, no sync)")
         self.gen_add_code_line("T U[6];")
         self.gen_add_code_line("#pragma unroll")
-        self.gen_add_code_line("for (int r = 0; r < 6; r++) { U[r] = s_U[%d + r]; }" % (8 * i))
+        self.gen_add_code_line("for (int r = 0; r < 6; r++) { U[r] = __shfl(IA_%d[r], %d, GRID_LANES_PER_SOLVE); }" % (i, IA0 + s))
         self.gen_add_code_line("const T Dinv = grid_rcp(U[%d]);" % s)
-        self.gen_add_code_line("if (lane == 0) { s_U[%d] = Dinv; }" % (8 * i + 6))
+        if keep_U_in_regs:
+            self.gen_add_code_line("#pragma unroll")
+            self.gen_add_code_line("for (int r = 0; r < 6; r++) { Uk[%d][r] = U[r]; }" % i)
+            self.gen_add_code_line("Dk[%d] = Dinv;" % i)
+        else:
+            self.gen_add_code_line("if (lane == 0) {", True)
+            self.gen_add_code_line("#pragma unroll")
+            self.gen_add_code_line("for (int r = 0; r < 6; r++) { s_U[%d + r] = U[r]; }" % (8 * i))
+            self.gen_add_code_line("s_U[%d] = Dinv;" % (8 * i + 6))
+            self.gen_add_end_control_flow()
         self.gen_add_code_line("const T m = ((lane == %d) ? Dinv : static_cast<T>(0)) - Dinv*F_%d[%d];" % (i, i, s))
         self.gen_add_code_line("Mcol[%d] = m; grid_pin(Mcol[%d]);" % (i, i))
         if bwd_hook is not None:
@@ -145,11 +154,14 @@ def gen_direct_minv_inner_body(self, use_thread_group=False, bwd_hook=None, fwd_
         self.gen_add_code_line("T Ff_%d[6];" % i)
         self.gen_add_code_line("{", True)
         self.gen_add_code_line("T X[18]; grid_load_X(X, &s_X[GRID_X_STRIDE*%d]);" % i)
-        self.gen_add_code_line("T U[6];")
-        self.gen_add_code_line("#pragma unroll")
-        self.gen_add_code_line("for (int r = 0; r < 6; r++) { U[r] = s_U[%d + r]; }" % (8 * i))
         self.gen_add_code_line("grid_xmul(Ff_%d, X, Ff_%d);" % (i, p))
-        self.gen_add_code_line("Mcol[%d] -= s_U[%d]*grid_dot6(U, Ff_%d); grid_pin(Mcol[%d]);" % (i, 8 * i + 6, i, i))
+        if keep_U_in_regs:
+            self.gen_add_code_line("Mcol[%d] -= Dk[%d]*grid_dot6(Uk[%d], Ff_%d); grid_pin(Mcol[%d]);" % (i, i, i, i, i))
+        else:
+            self.gen_add_code_line("{ T U[6];")
+            self.gen_add_code_line("  #pragma unroll")
+            self.gen_add_code_line("  for (int r = 0; r < 6; r++) { U[r] = s_U[%d + r]; }" % (8 * i))
+            self.gen_add_code_line("  Mcol[%d] -= s_U[%d]*grid_dot6(U, Ff_%d); grid_pin(Mcol[%d]); }" % (i, 8 * i + 6, i, i))
         if has_children:
             self.gen_add_code_line("Ff_%d[%d] += Mcol[%d];" % (i, s, i))
         self.gen_add_end_control_flow()

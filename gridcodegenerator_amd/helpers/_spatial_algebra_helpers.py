@@ -147,11 +147,14 @@ def gen_spatial_algebra_helpers(self):
     I*[w;v] = [Ibar w + h x v ; m v - h x w] costs 24 FMAs with 10 constants instead of a dense 36/36;
     a general symmetric 6x6 (e.g. a caller-supplied composite inertia) falls back to the dense form."""
     import os
+    lib = _SPATIAL_LIBRARY
+    if os.environ.get("GRID_NO_WAVE_BARRIER", "0") == "1":  # experiment: fences only
+        lib = lib.replace("    __builtin_amdgcn_wave_barrier();\n", "")
     store4 = "__builtin_memcpy(dst, v, 4*sizeof(T));"
     if os.environ.get("GRID_NT_STORE", "0") == "1":  # tuning knob: streaming (non-temporal) output stores
         store4 = ("typedef T vec4_t __attribute__((ext_vector_type(4), aligned(4))); vec4_t x = {v[0], v[1], v[2], v[3]}; "
                   "__builtin_nontemporal_store(x, reinterpret_cast<vec4_t *>(dst));")
-    for line in _SPATIAL_LIBRARY.replace("@@STORE4@@", store4).strip("\n").split("\n"):
+    for line in lib.replace("@@STORE4@@", store4).strip("\n").split("\n"):
         self.gen_add_code_line(line)
     self.gen_add_code_line("")
     m = self.model

@@ -83,6 +83,19 @@ void launch(dim3 grid, dim3 block, size_t smem_bytes, F &&body) {
 }  // namespace hipemu
 
 #define __builtin_amdgcn_rcpf(x) (1.0f / (x))
+// cross-lane shuffle inside groups of `width` consecutive threads (width-aligned): exchange through a scratch array
+namespace hipemu {
+inline float g_shfl[1024];
+inline float shfl(float v, int src, int width) {
+    const unsigned t = threadIdx.x + threadIdx.y * blockDim.x;
+    g_shfl[t] = v;
+    wave_barrier();
+    const float r = g_shfl[(t & ~(unsigned)(width - 1)) + (unsigned)src];
+    wave_barrier();
+    return r;
+}
+}  // namespace hipemu
+#define __shfl(v, src, width) hipemu::shfl((v), (src), (width))
 #define __builtin_amdgcn_fence(order, scope) ((void)0)
 #define __builtin_amdgcn_wave_barrier() hipemu::wave_barrier()
 #define hipLaunchKernelGGL(kernel, grid, block, smem, stream, ...) hipemu::launch((grid), (block), (smem), [&]() { kernel(__VA_ARGS__); })
