@@ -394,3 +394,33 @@ void FN(rbd_rnea_batch)(const model_t *m, int N, const real *q_qd, int stride, c
         FN(rbd_rnea)(m, in, in + n, qdd ? qdd + (size_t)k * n : NULL, gravity, c_out + (size_t)k * n, v, a, f);
     }
 }
+
+/* dc_du[k*2n^2 + col*n + row] from q_qd[k*stride + ...] (+ qdd[k*n+i] if qdd != NULL, else qdd = 0) */
+void FN(rbd_rnea_grad_batch)(const model_t *m, int N, const real *q_qd, int stride, const real *qdd, real gravity, real *dc_du_dev) {
+    int n = m->n;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static)
+#endif
+    for (int k = 0; k < N; k++) {
+        real out[2 * RBD_MAX_N * RBD_MAX_N], zero[RBD_MAX_N];
+        for (int i = 0; i < n; i++) zero[i] = 0;
+        const real *in = q_qd + (size_t)k * stride;
+        FN(rbd_rnea_grad)(m, in, in + n, qdd ? qdd + (size_t)k * n : zero, gravity, out);
+        real *dst = dc_du_dev + (size_t)k * 2 * n * n;
+        for (int col = 0; col < 2 * n; col++) for (int r = 0; r < n; r++) dst[col * n + r] = out[r * 2 * n + col];
+    }
+}
+
+/* Minv[k*n^2 + col*n + row], upper triangle (zeros below the diagonal) like the reference's direct_minv kernel */
+void FN(rbd_minv_batch)(const model_t *m, int N, const real *q, int stride, real *Minv_dev) {
+    int n = m->n;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static)
+#endif
+    for (int k = 0; k < N; k++) {
+        real out[RBD_MAX_N * RBD_MAX_N];
+        FN(rbd_minv)(m, q + (size_t)k * stride, out, 0);
+        real *dst = Minv_dev + (size_t)k * n * n;
+        for (int col = 0; col < n; col++) for (int r = 0; r < n; r++) dst[col * n + r] = out[r * n + col];
+    }
+}

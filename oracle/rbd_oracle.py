@@ -105,3 +105,20 @@ class Oracle:
         self._fn("rbd_rnea_batch")(ctypes.byref(self.model), ctypes.c_int(N), x.ctypes, ctypes.c_int(x.shape[1]),
                                    None if qdd_a is None else qdd_a.ctypes, self.creal(gravity), out.ctypes)
         return out
+
+    def rnea_grad_batch(self, q_qd, qdd=None, gravity=9.81):
+        """(N, >=2n) AoS (+ optional (N, n) qdd) -> (N, 2n*n) in the device layout dc_du[k][col*n+row]."""
+        x = self._a(q_qd)
+        N = x.shape[0]
+        qdd_a = None if qdd is None else self._a(qdd)
+        out = np.zeros((N, 2 * self.n * self.n), self.dtype)
+        self._fn("rbd_rnea_grad_batch")(ctypes.byref(self.model), ctypes.c_int(N), x.ctypes, ctypes.c_int(x.shape[1]),
+                                        None if qdd_a is None else qdd_a.ctypes, self.creal(gravity), out.ctypes)
+        return out
+
+    def minv_batch(self, q):
+        x = self._a(q)
+        N = x.shape[0]
+        out = np.zeros((N, self.n * self.n), self.dtype)
+        self._fn("rbd_minv_batch")(ctypes.byref(self.model), ctypes.c_int(N), x.ctypes, ctypes.c_int(x.shape[1]), out.ctypes)
+        return out
