@@ -68,6 +68,14 @@ class GRiDCodeGenerator:
         while lanes < need:
             lanes *= 2
         self.lanes_per_solve = lanes          # lane j of a group <-> joint j; 6 lanes also carry the articulated inertia columns
+        # derivative-walk form (see algorithms/_inverse_dynamics_gradient.py): VGPR-resident backward sweep for shallow trees, LDS-assisted
+        # forward accumulation for deep ones; and whether the gradient walk of forward_dynamics_gradient re-uses v, I v, fx(v) I v of the RNEA(qdd=0) pass
+        import os as _os
+        depth_max = max(self.model.depth) + 1
+        nslots = len(self.gen_gradient_slots())
+        mode = _os.environ.get("GRID_GRADIENT_WALK", "auto")
+        self.register_walk = (mode == "registers") or (mode == "auto" and depth_max * 6 * (1 + nslots) <= 200)
+        self.reuse_rnea = self.register_walk and n <= 9 and _os.environ.get("GRID_FUSE_FD", "1") == "1" and _os.environ.get("GRID_REUSE_RNEA", "0") == "1"  # measured: 16.6 us vs 15.0 us per launch with re-use (extra LDS traffic on the critical path), so off by default
         # tuning knob: minimum waves per SIMD the register allocator must leave room for (second __launch_bounds__ argument); 0 = compiler's choice
         self.min_waves_per_eu = int(__import__("os").environ.get("GRID_MIN_WAVES", "0"))
         self.suggested_threads = 256

@@ -77,7 +77,18 @@ def gen_forward_dynamics_inner(self, use_thread_group=False):
         else:
             self.gen_add_code_line("grid_xmul(rv[%d], X, rv[%d]); rv[%d][%d] += qd_r;" % (j, p, j, s))
             self.gen_add_code_line("grid_xmul(ra[%d], X, ra[%d]); grid_mxS_peq<T,%d>(ra[%d], rv[%d], qd_r);" % (j, p, s, j, j))
-        self.gen_add_code_line("T Iv[6]; grid_imul_%d(Iv, rv[%d]); grid_imul_%d(rf[%d], ra[%d]); grid_fxv_peq(rf[%d], rv[%d], Iv); grid_pin6(rf[%d]);" % (j, j, j, j, j, j, j, j))
+        if not self.reuse_rnea:
+            self.gen_add_code_line("T Iv[6]; grid_imul_%d(Iv, rv[%d]); grid_imul_%d(rf[%d], ra[%d]); grid_fxv_peq(rf[%d], rv[%d], Iv); grid_pin6(rf[%d]);" % (j, j, j, j, j, j, j, j))
+        else:
+            self.gen_add_code_line("T Iv[6], b[6]; grid_imul_%d(Iv, rv[%d]); grid_zero6(b); grid_fxv_peq(b, rv[%d], Iv); grid_imul_%d(rf[%d], ra[%d]);" % (j, j, j, j, j, j))
+            self.gen_add_code_line("#pragma unroll")
+            self.gen_add_code_line("for (int r = 0; r < 6; r++) { rf[%d][r] += b[r]; }" % j)
+            self.gen_add_code_line("grid_pin6(rf[%d]);" % j)
+            self.gen_add_code_line("// v, I v and fx(v) I v do not depend on qdd: keep them for the gradient walk (inverse_dynamics_gradient_inner_reuse)")
+            self.gen_add_code_line("if (lane == 0) {", True)
+            self.gen_add_code_line("#pragma unroll")
+            self.gen_add_code_line("for (int r = 0; r < 6; r++) { s_U[%d + r] = rv[%d][r]; s_U[%d + r] = Iv[r]; s_U[%d + r] = b[r]; }" % (18 * j, j, 18 * j + 6, 18 * j + 12))
+            self.gen_add_end_control_flow()
         self.gen_add_end_control_flow()
 
     def rnea_bwd_all():

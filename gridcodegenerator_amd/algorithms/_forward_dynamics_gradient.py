@@ -43,7 +43,7 @@ def gen_forward_dynamics_gradient_inner_python(self, use_thread_group=False, use
         self.gen_add_code_line("if (lane < %d) { %s[lane] = s_qdd[lane]; }" % (n, s_df_du_name))
         return
     self.gen_add_code_line(self.gen_gradient_outputs_decl())
-    self.gen_inverse_dynamics_gradient_inner_function_call(use_thread_group)
+    self.gen_inverse_dynamics_gradient_inner_function_call(use_thread_group, reuse=not use_qdd_Minv_input)
     if stop == 4:
         self.gen_dc_du_to_lds(s_df_du_name)
         return

@@ -57,9 +57,12 @@ def gen_gradient_slots(self):
     return slots
 
 
-def gen_inverse_dynamics_gradient_inner_function_call(self, use_thread_group=False, updated_var_names=None):
+def gen_inverse_dynamics_gradient_inner_function_call(self, use_thread_group=False, updated_var_names=None, reuse=False):
     outs = ", ".join("dc_" + sl["name"] for sl in self.gen_gradient_slots())
-    self.gen_add_code_line("inverse_dynamics_gradient_inner<T>(" + outs + ", s_qd, s_qdd, s_X, s_F, s_J, gravity, lane);")
+    if reuse and self.reuse_rnea:
+        self.gen_add_code_line("inverse_dynamics_gradient_inner_reuse<T>(" + outs + ", s_qd, s_qdd, s_X, s_U, s_J, gravity, lane);")
+    else:
+        self.gen_add_code_line("inverse_dynamics_gradient_inner<T>(" + outs + ", s_qd, s_qdd, s_X, s_F, s_J, gravity, lane);")
 
 
 def gen_gradient_outputs_decl(self):
@@ -67,7 +70,9 @@ def gen_gradient_outputs_decl(self):
     return "T " + ", ".join("dc_%s[%d]" % (sl["name"], n) for sl in self.gen_gradient_slots()) + ";"
 
 
-def gen_inverse_dynamics_gradient_inner(self, use_thread_group=False):
+def gen_inverse_dynamics_gradient_inner(self, use_thread_group=False, reuse=False):
+    """reuse=True emits inverse_dynamics_gradient_inner_reuse: same walk, but v, I v and fx(v) I v of every link are read from LDS
+    (s_F then points at the table forward_dynamics_inner left behind) instead of being recomputed."""
     m = self.model
     n = m.n
     G = self.lanes_per_solve
@@ -85,7 +90,7 @@ def gen_inverse_dynamics_gradient_inner(self, use_thread_group=False):
                            "gravity is the gravity constant", "lane is the caller's lane index inside the solve's lane group"], None)
     self.gen_add_code_line("template <typename T>")
     self.gen_add_code_line("__device__ __forceinline__")
-    self.gen_add_code_line("void inverse_dynamics_gradient_inner(" + ", ".join("T (&dc_%s)[%d]" % (sl["name"], n) for sl in slots) +
+    self.gen_add_code_line("void inverse_dynamics_gradient_inner" + ("_reuse" if reuse else "") + "(" + ", ".join("T (&dc_%s)[%d]" % (sl["name"], n) for sl in slots) +
                            ", const T *s_qd, const T *s_qdd, const T *s_X, T *s_F, T *s_J, const T gravity, const int lane) {", True)
     self.gen_add_code_line("const bool is_qd = (lane & 1) != 0; // odd columns are d/dqd, even columns d/dq")
     for sl in slots:
@@ -229,18 +234,30 @@ def gen_inverse_dynamics_gradient_inner(self, use_thread_group=False):
         self.gen_add_code_line("T X[18]; grid_load_X(X, &s_X[GRID_X_STRIDE*" + K + "]);")
         self.gen_add_code_line("const T qd = s_qd[" + K + "]; const T qdd = s_qdd[" + K + "];")
         self.gen_add_code_line("T Xa[6], Mxv[6], MxXa[6], Iv[6];")
+        if reuse:
+            self.gen_add_code_line("T b[6];")
+            self.gen_add_code_line("#pragma unroll")
+            self.gen_add_code_line("for (int r = 0; r < 6; r++) { v_%s[r] = s_F[%d + r]; Iv[r] = s_F[%d + r]; b[r] = s_F[%d + r]; }" % (K, 18 * k, 18 * k + 6, 18 * k + 12))
         if p == -1:
-            self.gen_add_code_line("grid_zero6(v_%s); v_%s[%d] = qd;" % (K, K, s))
+            if not reuse:
+                self.gen_add_code_line("grid_zero6(v_%s); v_%s[%d] = qd;" % (K, K, s))
             self.gen_add_code_line("grid_zero6(Xa); Xa[3] = X[2]*gravity; Xa[4] = X[5]*gravity; Xa[5] = X[8]*gravity;")
         else:
-            self.gen_add_code_line("grid_xmul(v_%s, X, v_%s); v_%s[%d] += qd;" % (K, P, K, s))
+            if not reuse:
+                self.gen_add_code_line("grid_xmul(v_%s, X, v_%s); v_%s[%d] += qd;" % (K, P, K, s))
             self.gen_add_code_line("grid_xmul(Xa, X, a_%s);" % P)
         self.gen_add_code_line("grid_zero6(Mxv); grid_mxS_peq<T,%d>(Mxv, v_%s, %s);" % (s, K, ONE))
         self.gen_add_code_line("grid_zero6(MxXa); grid_mxS_peq<T,%d>(MxXa, Xa, %s);" % (s, ONE))
         self.gen_add_code_line("#pragma unroll")
         self.gen_add_code_line("for (int r = 0; r < 6; r++) { a_%s[r] = Xa[r] + Mxv[r]*qd; }" % K)
         self.gen_add_code_line("a_%s[%d] += qdd;" % (K, s))
-        self.gen_add_code_line("grid_imul_%s(Iv, v_%s); grid_imul_%s(f_%s, a_%s); grid_fxv_peq(f_%s, v_%s, Iv); grid_pin6(f_%s);" % (K, K, K, K, K, K, K, K))
+        if reuse:
+            self.gen_add_code_line("grid_imul_%s(f_%s, a_%s);" % (K, K, K))
+            self.gen_add_code_line("#pragma unroll")
+            self.gen_add_code_line("for (int r = 0; r < 6; r++) { f_%s[r] += b[r]; }" % K)
+            self.gen_add_code_line("grid_pin6(f_%s);" % K)
+        else:
+            self.gen_add_code_line("grid_imul_%s(Iv, v_%s); grid_imul_%s(f_%s, a_%s); grid_fxv_peq(f_%s, v_%s, Iv); grid_pin6(f_%s);" % (K, K, K, K, K, K, K, K))
         for sl in act:
             c = sl["name"]
             is_own = sl is own
@@ -282,12 +299,9 @@ def gen_inverse_dynamics_gradient_inner(self, use_thread_group=False):
                 self.gen_add_code_line("grid_xtmul_peq(df%s_%s, X, df%s_%s); grid_pin6(df%s_%s);" % (sl["name"], P, sl["name"], K, sl["name"], P))
             self.gen_add_end_control_flow()
 
-    import os
-    depth_max = max(m.depth) + 1
-    mode = os.environ.get("GRID_GRADIENT_WALK", "auto")  # tuning knob: "registers" | "lds" | "auto"
-    use_regs = (mode == "registers") or (mode == "auto" and depth_max * 6 * (1 + len(slots)) <= 200)  # 30-DoF humanoid (180): 425 us vs 488 us per 16384 solves
+    use_regs = self.register_walk
     if use_regs:
-        self.gen_add_code_line("(void)s_F; (void)s_J; // the register-resident walk needs no LDS hand-offs")
+        self.gen_add_code_line("(void)s_F; (void)s_J; // the register-resident walk needs no LDS hand-offs" + (" (s_F is the read-only v / I v / fx(v) I v table here)" if reuse else ""))
         self.gen_tree_traversal(pre_reg, post_reg)
     else:
         self.gen_tree_traversal(pre, post)
@@ -430,6 +444,8 @@ def gen_inverse_dynamics_gradient_host(self, mode=0):
 
 def gen_inverse_dynamics_gradient(self, use_thread_group=False):
     self.gen_inverse_dynamics_gradient_inner(use_thread_group)
+    if self.reuse_rnea:
+        self.gen_inverse_dynamics_gradient_inner(use_thread_group, reuse=True)
     self.gen_inverse_dynamics_gradient_device(use_thread_group, use_qdd_input=False)
     self.gen_inverse_dynamics_gradient_device(use_thread_group, use_qdd_input=True)
     for use_qdd in (True, False):
