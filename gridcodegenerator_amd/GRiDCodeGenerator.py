@@ -78,6 +78,7 @@ class GRiDCodeGenerator:
         self.reuse_rnea = self.register_walk and n <= 9 and _os.environ.get("GRID_FUSE_FD", "1") == "1" and _os.environ.get("GRID_REUSE_RNEA", "0") == "1"  # measured: 16.6 us vs 15.0 us per launch with re-use (extra LDS traffic on the critical path), so off by default
         # tuning knob: minimum waves per SIMD the register allocator must leave room for (second __launch_bounds__ argument); 0 = compiler's choice
         self.min_waves_per_eu = int(__import__("os").environ.get("GRID_MIN_WAVES", "0"))
+        self.minv_ld = (n + 3) // 4 * 4  # leading dimension of the dense M^-1 in LDS
         self.suggested_threads = 256
         self.max_threads = 512                # __launch_bounds__: keeps 256 VGPRs available per lane
 
@@ -132,6 +133,7 @@ class GRiDCodeGenerator:
                                  "const int GRID_MAX_SOLVES_PER_BLOCK = SUGGESTED_THREADS/GRID_LANES_PER_SOLVE; // what the *_DYNAMIC_SHARED_MEM_COUNT constants cover",
                                  "// per-solve LDS slice (elements of T) and the offsets of its parts",
                                  "const int GRID_LDS_PER_SOLVE = " + str(lds["TOTAL"]) + ";",
+                                 "const int GRID_MINV_LD = " + str(self.minv_ld) + "; // leading dimension of the dense symmetric M^-1 kept in LDS (s_Minv[row*GRID_MINV_LD + col])",
                                  "const int GRID_OUT_PER_SOLVE = " + str(lds["OUT_PER_SOLVE"]) + "; // output staging per lane group, placed behind the block's slices",
                                  "// a block of t threads needs (t/GRID_LANES_PER_SOLVE)*(GRID_LDS_PER_SOLVE+GRID_OUT_PER_SOLVE)*sizeof(T) bytes of dynamic LDS;",
                                  "// the *_DYNAMIC_SHARED_MEM_COUNT constants below are that amount for SUGGESTED_THREADS"])

@@ -175,7 +175,7 @@ def gen_direct_minv_inner_body(self, use_thread_group=False, bwd_hook=None, fwd_
     self.gen_add_code_line("// publish: lane j writes the upper-triangle entries of its column and their mirror images")
     self.gen_add_code_line("if (lane < %d) {" % n, True)
     for i in range(n):
-        self.gen_add_code_line("if (lane >= %d) { s_Minv[%d + lane] = Mcol[%d]; s_Minv[lane*%d + %d] = Mcol[%d]; }" % (i, i * n, i, n, i, i))
+        self.gen_add_code_line("if (lane >= %d) { s_Minv[%d + lane] = Mcol[%d]; s_Minv[lane*%d + %d] = Mcol[%d]; }" % (i, i * self.minv_ld, i, self.minv_ld, i, i))
     self.gen_add_end_control_flow()
 
 
@@ -225,7 +225,7 @@ def gen_direct_minv_kernel(self, use_thread_group=False, single_call_timing=Fals
     self.gen_add_code_line("// upper triangle only in the output record")
     self.gen_add_parallel_loop("ind", str(n * n), use_thread_group)
     self.gen_add_code_line("const int row = ind %% %d; const int col = ind / %d;" % (n, n))
-    self.gen_add_code_line("s_out[ind] = (row <= col) ? s_Minv[ind] : static_cast<T>(0);")
+    self.gen_add_code_line("s_out[ind] = (row <= col) ? s_Minv[col*%d + row] : static_cast<T>(0);" % self.minv_ld)
     self.gen_add_end_control_flow()
     if single_call_timing:
         self.gen_kernel_save_result_single_timing("Minv", n * n, use_thread_group, "s_out")

@@ -28,7 +28,7 @@ def gen_forward_dynamics_finish(self, use_thread_group=False):
     self.gen_add_code_line("if (lane < %d) {" % n, True)
     self.gen_add_code_line("T val = static_cast<T>(0);")
     self.gen_add_code_line("#pragma unroll")
-    self.gen_add_code_line("for (int col = 0; col < %d; col++) { val += s_Minv[lane*%d + col]*(s_u[col] - c[col]); }" % (n, n))
+    self.gen_add_code_line("for (int col = 0; col < %d; col++) { val += s_Minv[lane*%d + col]*(s_u[col] - c[col]); }" % (n, self.minv_ld))
     self.gen_add_code_line("s_qdd[lane] = val;")
     self.gen_add_end_control_flow()
     self.gen_add_end_function()

@@ -324,7 +324,7 @@ def gen_dc_du_to_lds(self, dst="s_dc_du", minv_name=None):
             self.gen_add_code_line("for (int row = 0; row < %d; row++) {" % n, True)
             self.gen_add_code_line("T val = static_cast<T>(0);")
             self.gen_add_code_line("#pragma unroll")
-            self.gen_add_code_line("for (int i = 0; i < %d; i++) { val += %s[row*%d + i]*dc_%s[i]; }" % (n, minv_name, n, c))
+            self.gen_add_code_line("for (int i = 0; i < %d; i++) { val += %s[row*%d + i]*dc_%s[i]; }" % (n, minv_name, self.minv_ld, c))
             self.gen_add_code_line("%s[col*%d + row] = -val;" % (dst, n))
             self.gen_add_end_control_flow()
         self.gen_add_end_control_flow()

@@ -182,7 +182,7 @@ def gen_kernel_load_inputs(self, name, stride, amount, use_thread_group=False, n
         else:
             self.gen_add_code_line("// only the upper triangle of the caller's matrix is dereferenced (reference _forward_dynamics_gradient.py:54)")
             self.gen_add_code_line("const int row = ind % " + str(n) + "; const int col = ind / " + str(n) + ";")
-            self.gen_add_code_line("s_" + name3 + "[ind] = d_" + name3 + "_k[(row <= col) ? (col*" + str(n) + " + row) : (row*" + str(n) + " + col)];")
+            self.gen_add_code_line("s_" + name3 + "[row*" + str(self.minv_ld) + " + col] = d_" + name3 + "_k[(row <= col) ? (col*" + str(n) + " + row) : (row*" + str(n) + " + col)];")
         self.gen_add_end_control_flow()
     self.gen_add_sync(use_thread_group)
 

@@ -29,7 +29,7 @@ def gen_lds_layout(self):
                        ("X", 20 * n),                 # compact X(q): 18 of every 20
                        ("U", _pad4(18 * n) if self.reuse_rnea else 8 * n),  # U_i (6), 1/D_i, pad (deep/large robots); or v, I v, fx(v) I v of RNEA(qdd=0) kept for the gradient walk
                        ("T", 80),                     # 6x6 transpose scratch (row stride 6, 40 per buffer), double buffered by tree-depth parity
-                       ("MINV", _pad4(n * n)),        # dense symmetric M^-1 (col*n+row == row*n+col)
+                       ("MINV", n * _pad4(n)),        # dense symmetric M^-1, leading dimension padded to a multiple of 4 (16-byte aligned rows -> ds_read_b128)
                        ("QDD", _pad4(n)),
                        ("F", 0 if self.register_walk else _pad4(6 * n)),                # wave-uniform link forces parked between the two sweeps of the gradient walk
                        ("J", 0 if self.register_walk else 2 * _pad4(6 * n))):      # velocity Jacobian columns of the current link (published by the d/dqd lanes), double buffered
