@@ -14,9 +14,9 @@ _SPATIAL_LIBRARY = r"""
 // (which never straddles a wave) only needs the compiler fenced, not an s_barrier.
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ void grid_wave_sync() {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");  // LDS only: global loads/stores may still be scheduled across
     __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
 }
 
 // Returns x unchanged but opaque to the optimizer: used once per batch-loop iteration on the lane index so that

@@ -96,6 +96,6 @@ inline float shfl(float v, int src, int width) {
 }
 }  // namespace hipemu
 #define __shfl(v, src, width) hipemu::shfl((v), (src), (width))
-#define __builtin_amdgcn_fence(order, scope) ((void)0)
+#define __builtin_amdgcn_fence(...) ((void)0)
 #define __builtin_amdgcn_wave_barrier() hipemu::wave_barrier()
 #define hipLaunchKernelGGL(kernel, grid, block, smem, stream, ...) hipemu::launch((grid), (block), (smem), [&]() { kernel(__VA_ARGS__); })

@@ -61,6 +61,24 @@ def test_emulated_one_column_per_lane_variant(name, golden):
     assert per_solve_err(dc, np.stack([g["dc_du"][k].T.reshape(-1) for k in range(N)])) <= TOL
 
 
+@pytest.mark.parametrize("name,env", [("iiwa14", {"GRID_GRADIENT_WALK": "lds"}), ("hyq", {"GRID_GRADIENT_WALK": "lds"}), ("atlas", {"GRID_GRADIENT_WALK": "lds"}),
+                                      ("iiwa14", {"GRID_REUSE_RNEA": "1"}), ("iiwa14", {"GRID_FUSE_FD": "0"})])
+def test_emulated_generation_variants(name, env, golden):
+    """The non-default generated forms stay correct: LDS-assisted forward accumulation of the derivative walk (what deep trees get),
+    RNEA re-use, unfused forward dynamics."""
+    g = golden(name)
+    lib = emu_library(name, max_timesteps=64, env=env)
+    n = lib.n
+    N = 5
+    x = np.ascontiguousarray(np.hstack([g["q"], g["qd"], g["u"]]).astype(np.float32)[:N])
+    lib.set_launch_dims(0, 64)
+    out = lib.forward_dynamics_gradient_host(x)
+    assert per_solve_err(out, np.stack([g["df_du"][k].T.reshape(-1) for k in range(N)])) <= TOL
+    dc = np.zeros((N, 2 * n * n), np.float32)
+    lib.inverse_dynamics_gradient_device(x, np.ascontiguousarray(g["qdd"].astype(np.float32)[:N]), N, dc)
+    assert per_solve_err(dc, np.stack([g["dc_du"][k].T.reshape(-1) for k in range(N)])) <= TOL
+
+
 @pytest.mark.parametrize("blocks,threads", [(1, 64), (2, 24), (1, 8), (3, 40)])
 def test_emulated_ragged_launch_dims_and_grid_stride(blocks, threads, libs, golden):
     g = golden("iiwa14")

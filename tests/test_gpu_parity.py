@@ -220,3 +220,30 @@ def test_generated_host_api_float_and_double(torch_cuda, golden, tmp_path):
     assert per_solve_err(f64, ref) <= 1e-9  # fp64 kernel vs fp64 oracle (inputs are the same doubles)
     for line in out.splitlines():
         assert float(line.split("=")[-1]) <= (1e-4 if line.startswith("float") else 1e-9), line
+
+
+@pytest.mark.parametrize("env", [{"GRID_GRADIENT_WALK": "lds"}, {"GRID_COLS_PER_LANE": "1"}])
+def test_non_default_generation_variants_on_gpu(env, torch_cuda, golden, tmp_path):
+    """The generated forms that the shipped fixtures do not select by default (LDS-assisted forward accumulation for deep trees,
+    one derivative column per lane) are exercised on real wave64 hardware too: their LDS hand-offs rely on in-order LDS execution."""
+    import os
+
+    saved = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        so = build_library("iiwa14", build_dir=str(tmp_path))
+    finally:
+        for k, v in saved.items():
+            os.environ.pop(k, None) if v is None else os.environ.__setitem__(k, v)
+    lib = GridLibrary(so, device=0, max_timesteps=4096)
+    g = golden("iiwa14")
+    x = np.hstack([g["q"], g["qd"], g["u"]]).astype(np.float32)
+    out = run_fd_grad(torch_cuda, lib, x)
+    ref = np.stack([g["df_du"][k].T.reshape(-1) for k in range(x.shape[0])])
+    assert per_solve_err(out, ref) <= TOL
+    xs = inputs(7, 3000, seed=3)
+    from oracle.rbd_oracle import Oracle
+
+    ref2, _ = Oracle(RobotModel.from_fixture("iiwa14")).fd_grad_batch(xs.astype(np.float64))
+    assert per_solve_err(run_fd_grad(torch_cuda, lib, xs), ref2) <= TOL
+    lib.close()
