@@ -19,7 +19,8 @@ class GRiDCodeGenerator:
     # emission primitives, device math, model constants (free functions taking self, like the reference's layout)
     from .helpers import gen_add_code_line, gen_add_code_lines, gen_add_end_control_flow, gen_add_end_function, \
         gen_add_func_doc, gen_add_serial_ops, gen_add_parallel_loop, gen_add_sync, gen_var_in_list, gen_var_not_in_list, gen_add_multi_threaded_select, \
-        gen_lane_mask_test, gen_kernel_prologue, gen_kernel_load_inputs, gen_kernel_save_result, gen_kernel_save_result_single_timing, \
+        gen_lane_mask_test, gen_kernel_prologue, gen_kernel_load_inputs, gen_kernel_save_result, gen_kernel_load_inputs_single_timing, gen_kernel_save_result_single_timing, \
+        gen_static_array_ind_2d, gen_static_array_ind_3d, gen_add_debug_print_code_line, gen_add_debug_print_code_lines, \
         gen_spatial_algebra_helpers, gen_mx_func_call_for_cpp, \
         gen_lds_layout, gen_model_constant_table, gen_get_XI_size, gen_topology_helpers_size, gen_init_XImats, gen_init_topology_helpers, gen_init_robotModel, \
         gen_load_update_XImats_helpers_function_call, gen_load_update_XImats_helpers, gen_topology_sparsity_helpers_python, gen_topology_helpers_pointers_for_cpp

@@ -127,6 +127,12 @@ def gen_forward_dynamics_gradient_kernel(self, use_thread_group=False, use_qdd_M
         self.gen_add_code_line("for (int rep = 0; rep < NUM_TIMESTEPS; rep++){", True)
     self.gen_add_code_line("// compute")
     self.gen_forward_dynamics_gradient_device_function_call(compute_Minv=use_qdd_Minv_input)
+    if self.DEBUG_MODE and not single_call_timing:
+        # the reference's DEBUG_MODE prints the same-named intermediates of its NumPy oracle (reference _forward_dynamics_gradient.py:28-46)
+        self.gen_add_debug_print_code_lines(["printf(\"Minv\\n\");", "printMat<T,%d,%d>(s_Minv,GRID_MINV_LD);" % (n, n),
+                                             "printf(\"qdd\\n\");", "printMat<T,1,%d>(s_qdd,1);" % n,
+                                             "printf(\"df/dq\\n\");", "printMat<T,%d,%d>(&s_df_du[0],%d);" % (n, n, n),
+                                             "printf(\"df/dqd\\n\");", "printMat<T,%d,%d>(&s_df_du[%d],%d);" % (n, n, n * n, n)], use_thread_group)
     if single_call_timing:
         self.gen_add_end_control_flow()
     if single_call_timing:

@@ -187,6 +187,35 @@ def gen_kernel_load_inputs(self, name, stride, amount, use_thread_group=False, n
     self.gen_add_sync(use_thread_group)
 
 
+def gen_static_array_ind_2d(self, col, row, col_stride=6):
+    """Flat index of (row, col) in a column-major block (reference helpers/_code_generation_helpers.py:57)."""
+    return col_stride * col + row
+
+
+def gen_static_array_ind_3d(self, ind, col, row, ind_stride=36, col_stride=6):
+    """Flat index of (row, col) of the ind-th column-major block (reference helpers/_code_generation_helpers.py:60)."""
+    return ind_stride * ind + col_stride * col + row
+
+
+def gen_add_debug_print_code_line(self, print_code_string, use_thread_group=False):
+    self.gen_add_debug_print_code_lines([print_code_string], use_thread_group)
+
+
+def gen_add_debug_print_code_lines(self, print_code_string_arr, use_thread_group=False):
+    """printf/printMat lines executed by lane 0 of the lane group that owns solve 0 (reference: thread 0 of block 0)."""
+    self.gen_add_sync(use_thread_group)
+    self.gen_add_code_line("if (lane == 0 && k == 0) {", True)
+    for line in print_code_string_arr:
+        self.gen_add_code_line(line)
+    self.gen_add_end_control_flow()
+    self.gen_add_sync(use_thread_group)
+
+
+def gen_kernel_load_inputs_single_timing(self, name, amount, use_thread_group=False, name2=None, amount2=1, name3=None, amount3=1):
+    """Timing kernels read ONE solve (record 0): same staging as gen_kernel_load_inputs with kc == 0."""
+    self.gen_kernel_load_inputs(name, 0, amount, use_thread_group, name2, 0, amount2, name3, 0, amount3)
+
+
 def gen_kernel_save_result_single_timing(self, store_to_name, amount, use_thread_group=False, load_from_name=None):
     """Timing kernels run ONE solve on ONE lane group: plain lane-strided store of its record."""
     if load_from_name is None:

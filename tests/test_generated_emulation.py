@@ -163,3 +163,18 @@ def test_generator_rejects_unsupported_robots():
         GRiDCodeGenerator(Floating(RobotModel.from_fixture("iiwa14").desc))
     with pytest.raises(NotImplementedError):
         GRiDCodeGenerator(RobotModel.from_fixture("iiwa14")).gen_all_code(use_thread_group=True)
+
+
+def test_emulated_error_behaviour(libs):
+    """C-ABI error returns instead of the reference's print-and-exit (GRiDCodeGenerator.py:279-286)."""
+    from gridcodegenerator_amd.runtime import GridError
+
+    lib = libs("iiwa14")  # created with max_timesteps=128
+    with pytest.raises(GridError):
+        lib.forward_dynamics_gradient_host(np.zeros((129, 21), np.float32))  # more solves than grid_init reserved
+    with pytest.raises(ValueError):
+        lib.forward_dynamics_gradient_host(np.zeros((4, 20), np.float32))  # wrong record length
+    with pytest.raises(GridError):
+        lib.forward_dynamics_gradient_device(np.zeros((4, 21), np.float32), -1, np.zeros((4, 98), np.float32))  # negative batch
+    out = lib.forward_dynamics_gradient_host(np.zeros((1, 21), np.float32))  # still usable afterwards
+    assert np.isfinite(out).all()
