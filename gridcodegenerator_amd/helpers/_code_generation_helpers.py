@@ -165,7 +165,7 @@ def gen_kernel_load_inputs(self, name, stride, amount, use_thread_group=False, n
         if nm is None:
             continue
         trips = (int(am) + G - 1) // G
-        self.gen_add_code_line("const T *d_" + nm + "_k = &d_" + nm + "[kc*" + str(st) + "];")
+        self.gen_add_code_line("const T *d_" + nm + "_k = &d_" + nm + "[static_cast<size_t>(kc)*" + str(st) + "];")
         self.gen_add_code_line("{ // all global loads are issued before the first LDS write (one memory latency instead of %d)" % trips)
         self.gen_add_code_line("  T r_in[%d];" % trips)
         self.gen_add_code_line("  #pragma unroll")
@@ -175,7 +175,7 @@ def gen_kernel_load_inputs(self, name, stride, amount, use_thread_group=False, n
         self.gen_add_code_line("}")
     if name3 is not None:
         n = symmetrize3
-        self.gen_add_code_line("const T *d_" + name3 + "_k = &d_" + name3 + "[kc*" + str(stride3) + "];")
+        self.gen_add_code_line("const T *d_" + name3 + "_k = &d_" + name3 + "[static_cast<size_t>(kc)*" + str(stride3) + "];")
         self.gen_add_parallel_loop("ind", str(amount3), use_thread_group)
         if n is None:
             self.gen_add_code_line("s_" + name3 + "[ind] = d_" + name3 + "_k[ind];")
@@ -241,7 +241,7 @@ def gen_kernel_save_result(self, store_to_name, stride, amount, use_thread_group
                              "int nv = NUM_TIMESTEPS_OUT - (k - grp + gw0); { const int ng = gpb - gw0; nv = nv < ng ? nv : ng; nv = nv < GRID_SOLVES_PER_WAVE ? nv : GRID_SOLVES_PER_WAVE; }",
                              "const int total = nv*" + str(amount) + "; // elements this wave writes",
                              "const T *src = " + load_from_name + " - (grp - gw0)*" + str(amount) + ";",
-                             "T *dst = &d_" + store_to_name + "[(k - grp + gw0)*" + str(amount) + "];",
+                             "T *dst = &d_" + store_to_name + "[static_cast<size_t>(k - grp + gw0)*" + str(amount) + "];",
                              "const int wl = tid & 63;",
                              "for (int e = 4*wl; e + 3 < total; e += 256) { T tmp[4]; __builtin_memcpy(tmp, __builtin_assume_aligned(src + e, 4*sizeof(T) < 16 ? 4*sizeof(T) : 16), 4*sizeof(T)); grid_store4(dst + e, tmp); }",
                              "{ const int e = (total & ~3) + wl; if (wl < 3 && e < total) { dst[e] = src[e]; } }"])
