@@ -162,10 +162,13 @@ void FN(rbd_rnea)(const model_t *m, const real *q, const real *qd, const real *q
  * Minv is n x n row-major.  dense != 0 fills the lower triangle by symmetry. */
 static void minv_core(const model_t *m, const real *Xs, real *Minv, int dense) {
     int n = m->n;
-    real *F = (real *)calloc((size_t)n * 6 * n, sizeof(real)); /* F[i][row][col] */
-    real *U = (real *)calloc((size_t)n * 6, sizeof(real));
-    real *IA = (real *)malloc((size_t)n * 36 * sizeof(real));
+    /* C99 variable-length arrays: no allocator traffic in the timed multi-threaded baseline */
+    real F[(size_t)n * 6 * n]; /* F[i][row][col] */
+    real U[(size_t)n * 6];
+    real IA[(size_t)n * 36];
     real Dinv[RBD_MAX_N];
+    memset(F, 0, sizeof(F));
+    memset(U, 0, sizeof(U));
     memcpy(IA, m->I, (size_t)n * 36 * sizeof(real));
     memset(Minv, 0, (size_t)n * n * sizeof(real));
 #define Fm(i, r, c) F[((size_t)(i) * 6 + (r)) * n + (c)]
@@ -216,7 +219,6 @@ static void minv_core(const model_t *m, const real *Xs, real *Minv, int dense) {
     }
     if (dense) for (int r = 0; r < n; r++) for (int c2 = 0; c2 < r; c2++) Minv[r * n + c2] = Minv[c2 * n + r];
 #undef Fm
-    free(F); free(U); free(IA);
 }
 
 void FN(rbd_minv)(const model_t *m, const real *q, real *Minv, int dense) {
@@ -231,7 +233,9 @@ static void rnea_grad_core(const model_t *m, const real *Xs, const real *qd, con
                            real gravity, real *dc_du) {
     int n = m->n;
     size_t sz = (size_t)6 * n * n;
-    real *dv_dq = (real *)calloc(sz * 6, sizeof(real));
+    real dbuf[sz * 6];
+    memset(dbuf, 0, sizeof(dbuf));
+    real *dv_dq = dbuf;
     real *dv_dqd = dv_dq + sz, *da_dq = dv_dq + 2 * sz, *da_dqd = dv_dq + 3 * sz, *df_dq = dv_dq + 4 * sz, *df_dqd = dv_dq + 5 * sz;
 #define D(arr, row, col, ind) arr[((size_t)(ind) * n + (col)) * 6 + (row)] /* column vectors contiguous */
     real MxXv[6 * RBD_MAX_N], MxXa[6 * RBD_MAX_N], Mxv[6 * RBD_MAX_N], Mxf[6 * RBD_MAX_N], Iv[6 * RBD_MAX_N];
@@ -326,7 +330,6 @@ static void rnea_grad_core(const model_t *m, const real *Xs, const real *qd, con
         }
     }
 #undef D
-    free(dv_dq);
 }
 
 void FN(rbd_rnea_grad)(const model_t *m, const real *q, const real *qd, const real *qdd, real gravity, real *dc_du) {
@@ -343,8 +346,8 @@ void FN(rbd_fd_grad)(const model_t *m, const real *q, const real *qd, const real
                      real *df_du, real *qdd_out, real *Minv_out, real *dc_du_out) {
     int n = m->n;
     real Xs[36 * RBD_MAX_N], c[RBD_MAX_N], v[6 * RBD_MAX_N], a[6 * RBD_MAX_N], f[6 * RBD_MAX_N], qdd[RBD_MAX_N];
-    real *Minv = (real *)malloc((size_t)n * n * sizeof(real));
-    real *dc_du = (real *)malloc((size_t)n * 2 * n * sizeof(real));
+    real Minv[(size_t)n * n];
+    real dc_du[(size_t)n * 2 * n];
     for (int i = 0; i < n; i++) Xmat(m, i, q[i], Xs + 36 * i);
     rnea_core(m, Xs, qd, NULL, gravity, c, v, a, f);
     minv_core(m, Xs, Minv, 1);
@@ -359,7 +362,6 @@ void FN(rbd_fd_grad)(const model_t *m, const real *q, const real *qd, const real
     if (qdd_out) memcpy(qdd_out, qdd, (size_t)n * sizeof(real));
     if (Minv_out) memcpy(Minv_out, Minv, (size_t)n * n * sizeof(real));
     if (dc_du_out) memcpy(dc_du_out, dc_du, (size_t)n * 2 * n * sizeof(real));
-    free(Minv); free(dc_du);
 }
 
 /* ---------------- batch drivers in the DEVICE layouts --------------------
