@@ -46,18 +46,31 @@ def cpu_baseline(robot, x, budget_s=12.0):
         so = None
     orc = rbd_oracle.Oracle(robot, dtype=np.float32, lib_path=so)
     sample = x  # the whole bench batch per call (enough work per thread for the static OpenMP split)
-    orc.fd_grad_batch(sample, nthreads=0)  # warm
-    _, cores = orc.fd_grad_batch(sample, nthreads=0)
+    # the job may own fewer CPUs than the host shows (a 1-GPU box gets a share of the host): pick the thread count that is
+    # actually fastest from a short sweep, then time the bounded sample with it; `cores` reports the threads used
+    avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    best_nt, best_rate = 1, 0.0
+    for nt in sorted(set(min(avail, c) for c in (4, 8, 16, 32, 64, 128, avail))):
+        orc.fd_grad_batch(sample, nthreads=nt)
+        t0 = time.perf_counter()
+        k = 0
+        while time.perf_counter() - t0 < 0.4:
+            orc.fd_grad_batch(sample, nthreads=nt)
+            k += 1
+        rate = k / (time.perf_counter() - t0)
+        if rate > best_rate:
+            best_nt, best_rate = nt, rate
+    cores = best_nt
     reps = 0
     t0 = time.perf_counter()
     while True:  # time-bounded sample (~budget_s of CPU work), whatever the host's load
-        orc.fd_grad_batch(sample, nthreads=0)
+        orc.fd_grad_batch(sample, nthreads=cores)
         reps += 1
         dt = time.perf_counter() - t0
-        if dt >= budget_s or reps >= 5000:
+        if dt >= budget_s or reps >= 20000:
             break
     return {"value": reps * sample.shape[0] / dt, "unit": "solves/s", "cores": int(cores), "kind": "port",
-            "sample": "%d x %d iiwa14 solves of the bench batch, fp32 C oracle (oracle/rbd_oracle.c, -O3 -march=native, OpenMP static), %.1f s" % (reps, sample.shape[0], dt)}
+            "sample": "%d x %d iiwa14 solves of the bench batch, fp32 C oracle (oracle/rbd_oracle.c, -O3 -march=native, OpenMP static, best of a thread-count sweep on %d visible CPUs), %.1f s" % (reps, sample.shape[0], avail, dt)}
 
 
 def shard_seed(rank):
