@@ -108,6 +108,9 @@ def gen_forward_dynamics_gradient_kernel(self, use_thread_group=False, use_qdd_M
     self.gen_add_code_line("__global__ GRID_LAUNCH_BOUNDS")
     self.gen_add_code_line(func_def, True)
     self.gen_kernel_prologue("GRID_LDS_PER_SOLVE")
+    import os
+    if os.environ.get("GRID_DEBUG_STOP", "0") == "9":  # timing ablation only: an empty kernel (launch + dispatch cost)
+        self.gen_add_code_line("if (NUM_TIMESTEPS > -1) {return;}")
     if use_qdd_Minv_input:
         self.gen_add_code_line("T *s_q_qd = &s_mem[GRID_OFF_IN]; T *s_q = s_q_qd; T *s_qd = &s_q_qd[%d]; T *s_qdd = &s_mem[GRID_OFF_QDD];" % n)
     else:
