@@ -154,6 +154,9 @@ def gen_spatial_algebra_helpers(self):
     if os.environ.get("GRID_PIN_VOLATILE", "1") == "0":  # experiment: pins as plain (movable) asm
         lib = lib.replace('__device__ __forceinline__ void grid_pin(T &x) { asm("" : "+v"(x)); }', '__device__ __forceinline__ void grid_pin(T &x) { asm("" : "+v"(x)); }')
         lib = lib.replace('for (int r = 0; r < 6; r++) { asm("" : "+v"(v[r])); }', 'for (int r = 0; r < 6; r++) { asm("" : "+v"(v[r])); }')
+    if os.environ.get("GRID_NO_PINS", "0") == "1":  # experiment: no pins at all
+        lib = lib.replace('__device__ __forceinline__ void grid_pin(T &x) { asm("" : "+v"(x)); }', '__device__ __forceinline__ void grid_pin(T &x) { (void)x; }')
+        lib = lib.replace('for (int r = 0; r < 6; r++) { asm("" : "+v"(v[r])); }', 'for (int r = 0; r < 6; r++) { (void)v[r]; }')
     if os.environ.get("GRID_NO_WAVE_BARRIER", "0") == "1":  # experiment: fences only
         lib = lib.replace("    __builtin_amdgcn_wave_barrier();\n", "")
     store4 = "__builtin_memcpy(dst, v, 4*sizeof(T));"
