@@ -14,9 +14,11 @@ _SPATIAL_LIBRARY = r"""
 // (which never straddles a wave) only needs the compiler fenced, not an s_barrier.
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ void grid_wave_sync() {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");  // LDS only: global loads/stores may still be scheduled across
+    // (an LDS-only fence - third argument "local" - was tried: it lets the compiler hoist the 6n global loads of the inertia columns
+    //  above every sync, which costs 900 B of scratch per lane on the 30-DoF robot and gains nothing on the 7-DoF one)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
 // Returns x unchanged but opaque to the optimizer: used once per batch-loop iteration on the lane index so that
