@@ -39,7 +39,9 @@ class GRiDCodeGenerator:
         gen_inverse_dynamics_gradient_device, gen_inverse_dynamics_gradient_kernel, gen_inverse_dynamics_gradient_host, gen_inverse_dynamics_gradient, \
         gen_forward_dynamics_gradient_inner_temp_mem_size, gen_forward_dynamics_gradient_kernel_max_temp_mem_size, \
         gen_forward_dynamics_gradient_inner_python, gen_forward_dynamics_gradient_device, gen_forward_dynamics_gradient_kernel, \
-        gen_forward_dynamics_gradient_host, gen_forward_dynamics_gradient, gen_forward_dynamics_gradient_device_function_call
+        gen_forward_dynamics_gradient_host, gen_forward_dynamics_gradient, gen_forward_dynamics_gradient_device_function_call, \
+        gen_tip_frame_link_constants, gen_tip_frame_joint_offset, gen_tip_frame_library, gen_forward_dynamics_gradient_inner_tip, \
+        gen_forward_dynamics_gradient_inner_tip_function_call, gen_tip_frame_gradient
 
     # NumPy debug helpers with the reference's names and signatures (reference GRiDCodeGenerator.py:50-51, README "Additional Features")
     from ._test import test_rnea, test_minv, test_rnea_grad, test_fd_grad
@@ -75,7 +77,16 @@ class GRiDCodeGenerator:
         depth_max = max(self.model.depth) + 1
         nslots = len(self.gen_gradient_slots())
         mode = _os.environ.get("GRID_GRADIENT_WALK", "auto")
-        self.register_walk = (mode == "registers") or (mode == "auto" and depth_max * 6 * (1 + nslots) <= 200)
+        if mode not in ("auto", "registers", "lds", "tipframe"):
+            raise ValueError("GRID_GRADIENT_WALK must be auto, registers, lds or tipframe")
+        self.register_walk = (mode == "registers") or (mode in ("auto", "tipframe") and depth_max * 6 * (1 + nslots) <= 200)
+        # forward_dynamics_gradient of serial revolute chains is assembled in the tip link's frame (algorithms/_tip_frame_gradient.py);
+        # every other robot, and every other kernel, uses the column walk selected above
+        m_ = self.model
+        tip_ok = (all(m_.parent[j] == j - 1 for j in range(n)) and all(s_ < 3 for s_ in m_.S_index) and COLS_PER_LANE == 2 and lanes <= 16)
+        if mode == "tipframe" and not tip_ok:
+            raise NotImplementedError("GRID_GRADIENT_WALK=tipframe needs a serial chain of revolute joints with at most 16 joints")
+        self.tip_frame = tip_ok and mode in ("auto", "tipframe")
         self.reuse_rnea = self.register_walk and n <= 9 and _os.environ.get("GRID_FUSE_FD", "1") == "1" and _os.environ.get("GRID_REUSE_RNEA", "0") == "1"  # measured: 16.6 us vs 15.0 us per launch with re-use (extra LDS traffic on the critical path), so off by default
         # tuning knob: minimum waves per SIMD the register allocator must leave room for (second __launch_bounds__ argument); 0 = compiler's choice
         self.min_waves_per_eu = int(__import__("os").environ.get("GRID_MIN_WAVES", "0"))
@@ -270,6 +281,8 @@ class GRiDCodeGenerator:
         self.gen_add_code_line("namespace " + self.file_namespace + " {", True)
         self.gen_add_constants_helpers(include_base_inertia, include_homogenous_transforms)
         self.gen_spatial_algebra_helpers()
+        if self.tip_frame:
+            self.gen_tip_frame_library()
         self.gen_model_constant_table()
         self.gen_init_topology_helpers()
         self.gen_init_XImats(include_base_inertia, include_homogenous_transforms)
@@ -281,6 +294,8 @@ class GRiDCodeGenerator:
         self.gen_direct_minv(use_thread_group)
         self.gen_forward_dynamics(use_thread_group)
         self.gen_inverse_dynamics_gradient(use_thread_group)
+        if self.tip_frame:
+            self.gen_tip_frame_gradient(use_thread_group)
         self.gen_forward_dynamics_gradient(use_thread_group)
         self.gen_init_close_grid()
         self.gen_add_end_control_flow()

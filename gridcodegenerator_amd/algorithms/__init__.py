@@ -3,3 +3,5 @@ from ._direct_minv import *
 from ._forward_dynamics import *
 from ._inverse_dynamics_gradient import *
 from ._forward_dynamics_gradient import *
+from ._tip_frame_gradient import gen_tip_frame_link_constants, gen_tip_frame_joint_offset, gen_tip_frame_library, \
+    gen_forward_dynamics_gradient_inner_tip, gen_forward_dynamics_gradient_inner_tip_function_call, gen_tip_frame_gradient

@@ -1,0 +1,426 @@
+"""Forward-dynamics gradient for serial revolute chains in ONE common frame (the tip link's), emitter for the HIP/CDNA4 backend.
+
+Same function as the column walk of algorithms/_inverse_dynamics_gradient.py (reference algorithms/_inverse_dynamics_gradient.py:27-775
+and _forward_dynamics_gradient.py:7-62; oracle /root/reference/_test.py:229-520), different algorithm: instead of pushing 2n derivative
+columns through every link transform (O(n d) 6x6 transforms), all link quantities are expressed once in a single frame F and the
+partial derivatives of RNEA are assembled from per-joint vectors by dot products (the inverse-dynamics derivative identities of
+Singh, Russell & Wensing, "Efficient Analytical Derivatives of Rigid-Body Dynamics using Spatial Vector Algebra", RA-L 2022):
+
+    with  Pd_j  = v_j x S_j,  Pdd_j = a_j x S_j + v_j x Pd_j  (motion cross products, all vectors in F coordinates)
+          I^C, B^C, f^C = sums over the links j..n-1 of  I_k,  B(I_k, v_k) = (v x*) I - I (v x) + (I v) xbar*,  f_k = I_k a_k + v_k x* I_k v_k
+          t1 = I^C S_j   t2 = B^C S_j + 2 I^C Pd_j   t3 = B^C Pd_j + I^C Pdd_j + S_j x* f^C   t4 = (B^C)^T S_j
+    for k <= j:   d c_k/d q_j = S_k . t3_j                 d c_k/d qd_j = S_k . t2_j
+    for k >  j:   d c_k/d q_j = t1_k . Pdd_j + t4_k . Pd_j   d c_k/d qd_j = 2 t1_k . Pd_j + t4_k . S_j
+    B(I, v) of a rigid body is [[Sym - n~, 0], [-2 l~, 0]] with [n; l] = I v and Sym = w~ Ibar + (w~ Ibar)^T - h u^T - u h^T + 2 (u.h) 1,
+    i.e. 12 numbers, and I^C stays a 10-parameter rigid-body inertia.
+
+Why the TIP frame: every d c_k/d u_j is later multiplied by M^-1, whose entries are ~1e3 for the light wrist links and ~1 for the
+base links.  In the world frame the wrist rows are small differences of large moments about a far-away origin and fp32 loses
+4 digits (measured: max error 1.8e-4 of max|df/du| on the 7-DoF arm); with the origin at the tip the same rows are computed
+about a nearby origin and the error is that of the link-local recursion (3e-6).  F is the inertial frame that coincides with
+the tip link at this instant, so all identities hold unchanged.
+
+Lane mapping (chain: lane j <-> joint j, parent = lane j-1): the frame chain tip -> base runs wave-uniformly inside the M^-1
+backward sweep (same joint order, shares its X loads), every lane keeps its own (R_j, p_j); prefix sums over the ancestors
+(v, a) and suffix sums over the subtree (I^C, B^C, f^C) are log-step DPP scans inside the lane group; the only LDS hand-offs are
+tau - c (n floats) and one 16-float record per joint [S | t1 | t4] that every lane reads to assemble its two columns.
+
+Scope: serial chains of revolute joints (the reference's own iiwa case).  Robots with prismatic joints stay on the column walk: the
+reference's oracle differs from the true derivative for non-root prismatic joints (checked by finite differences of its own RNEA),
+and parity with the reference is the contract.
+"""
+import numpy as np
+
+
+def gen_tip_frame_link_constants(self):
+    """Per-lane table rows appended to grid_model_constants: [Ic_xx Ic_xy Ic_xz Ic_yy Ic_yz Ic_zz | c_x c_y c_z | m | damping | S axis];
+    rows of lanes that hold no joint are zero (all suffix-summed quantities are linear in the inertia, so they contribute nothing)."""
+    m = self.model
+    rows = []
+    for j in range(self.lanes_per_solve):
+        if j >= m.n:
+            rows += [0.0] * 12
+            continue
+        I = m.I[j]
+        mass = I[3, 3]
+        H = I[:3, 3:]
+        h = np.array([H[2, 1], H[0, 2], H[1, 0]])
+        c = h / mass
+        Ic = I[:3, :3] - mass * (float(c @ c) * np.eye(3) - np.outer(c, c))
+        rows += [Ic[0, 0], Ic[0, 1], Ic[0, 2], Ic[1, 1], Ic[1, 2], Ic[2, 2], c[0], c[1], c[2], mass, float(m.damping[j]), float(m.S_index[j])]
+    return rows
+
+
+def gen_tip_frame_joint_offset(self, j):
+    """Origin of frame j in the coordinates of its parent frame (constant for a revolute joint): X_tree = [[E,0],[-E r~,E]] -> r."""
+    XT = self.model.X_tree[j]
+    E, B = XT[:3, :3], XT[3:, :3]
+    rx = -E.T @ B
+    r = np.array([rx[2, 1], rx[0, 2], rx[1, 0]])
+    return np.where(np.abs(r) < 1e-12, 0.0, r)
+
+
+_TIP_LIBRARY = r"""
+// ---------------------------------------------------------------------------------------------------------------------
+// tip-frame gradient path (serial revolute chains): cross-lane moves, scans, 10-parameter inertias
+// ---------------------------------------------------------------------------------------------------------------------
+// value held CTRL-encoded lanes away inside the 16-lane DPP row (0 when that lane is outside the row); no LDS traffic
+template <int CTRL> __device__ __forceinline__ float grid_dpp_mov(const float x) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xf, 0xf, true));
+}
+template <int CTRL> __device__ __forceinline__ double grid_dpp_mov(const double x) {
+    const unsigned long long b = __builtin_bit_cast(unsigned long long, x);
+    const unsigned int lo = static_cast<unsigned int>(__builtin_amdgcn_update_dpp(0, static_cast<int>(static_cast<unsigned int>(b)), CTRL, 0xf, 0xf, true));
+    const unsigned int hi = static_cast<unsigned int>(__builtin_amdgcn_update_dpp(0, static_cast<int>(static_cast<unsigned int>(b >> 32)), CTRL, 0xf, 0xf, true));
+    return __builtin_bit_cast(double, (static_cast<unsigned long long>(hi) << 32) | lo);
+}
+template <int K, typename T> __device__ __forceinline__ T grid_lane_below(const T x) { return grid_dpp_mov<0x110 + K>(x); }  // row_shr:K : from lane - K
+template <int K, typename T> __device__ __forceinline__ T grid_lane_above(const T x) { return grid_dpp_mov<0x100 + K>(x); }  // row_shl:K : from lane + K
+
+// y = a x b for motion vectors ([w;v]): [wa x wb ; wa x vb + va x wb]
+template <typename T>
+__device__ __forceinline__ void grid_mxm(T (&y)[6], const T (&a)[6], const T (&b)[6]) {
+    y[0] = a[1]*b[2] - a[2]*b[1];
+    y[1] = a[2]*b[0] - a[0]*b[2];
+    y[2] = a[0]*b[1] - a[1]*b[0];
+    y[3] = a[1]*b[5] - a[2]*b[4] + a[4]*b[2] - a[5]*b[1];
+    y[4] = a[2]*b[3] - a[0]*b[5] + a[5]*b[0] - a[3]*b[2];
+    y[5] = a[0]*b[4] - a[1]*b[3] + a[3]*b[1] - a[4]*b[0];
+}
+template <typename T>
+__device__ __forceinline__ void grid_mxm_peq(T (&y)[6], const T (&a)[6], const T (&b)[6]) {
+    y[0] += a[1]*b[2] - a[2]*b[1];
+    y[1] += a[2]*b[0] - a[0]*b[2];
+    y[2] += a[0]*b[1] - a[1]*b[0];
+    y[3] += a[1]*b[5] - a[2]*b[4] + a[4]*b[2] - a[5]*b[1];
+    y[4] += a[2]*b[3] - a[0]*b[5] + a[5]*b[0] - a[3]*b[2];
+    y[5] += a[0]*b[4] - a[1]*b[3] + a[3]*b[1] - a[4]*b[0];
+}
+
+// rigid-body inertia about the origin of the working frame, I = [Ixx Ixy Ixz Iyy Iyz Izz | hx hy hz | m]:  y (+)= I x = [Ibar w + h x u ; m u - h x w]
+template <typename T>
+__device__ __forceinline__ void grid_rbi_mul(T (&y)[6], const T (&I)[10], const T (&x)[6]) {
+    y[0] = I[0]*x[0] + I[1]*x[1] + I[2]*x[2] + I[7]*x[5] - I[8]*x[4];
+    y[1] = I[1]*x[0] + I[3]*x[1] + I[4]*x[2] + I[8]*x[3] - I[6]*x[5];
+    y[2] = I[2]*x[0] + I[4]*x[1] + I[5]*x[2] + I[6]*x[4] - I[7]*x[3];
+    y[3] = I[9]*x[3] - I[7]*x[2] + I[8]*x[1];
+    y[4] = I[9]*x[4] - I[8]*x[0] + I[6]*x[2];
+    y[5] = I[9]*x[5] - I[6]*x[1] + I[7]*x[0];
+}
+template <typename T>
+__device__ __forceinline__ void grid_rbi_mul_peq(T (&y)[6], const T (&I)[10], const T (&x)[6], const T alpha) {
+    y[0] += alpha*(I[0]*x[0] + I[1]*x[1] + I[2]*x[2] + I[7]*x[5] - I[8]*x[4]);
+    y[1] += alpha*(I[1]*x[0] + I[3]*x[1] + I[4]*x[2] + I[8]*x[3] - I[6]*x[5]);
+    y[2] += alpha*(I[2]*x[0] + I[4]*x[1] + I[5]*x[2] + I[6]*x[4] - I[7]*x[3]);
+    y[3] += alpha*(I[9]*x[3] - I[7]*x[2] + I[8]*x[1]);
+    y[4] += alpha*(I[9]*x[4] - I[8]*x[0] + I[6]*x[2]);
+    y[5] += alpha*(I[9]*x[5] - I[6]*x[1] + I[7]*x[0]);
+}
+
+// body-level Coriolis matrix B = [[Sym - n~, 0], [-2 l~, 0]] stored as [Sxx Sxy Sxz Syy Syz Szz | nx ny nz | lx ly lz]
+// y = B x : only the angular part of x matters
+template <typename T>
+__device__ __forceinline__ void grid_bmul(T (&y)[6], const T (&B)[12], const T (&x)[6]) {
+    y[0] = B[0]*x[0] + B[1]*x[1] + B[2]*x[2] - (B[7]*x[2] - B[8]*x[1]);
+    y[1] = B[1]*x[0] + B[3]*x[1] + B[4]*x[2] - (B[8]*x[0] - B[6]*x[2]);
+    y[2] = B[2]*x[0] + B[4]*x[1] + B[5]*x[2] - (B[6]*x[1] - B[7]*x[0]);
+    y[3] = static_cast<T>(-2)*(B[10]*x[2] - B[11]*x[1]);
+    y[4] = static_cast<T>(-2)*(B[11]*x[0] - B[9]*x[2]);
+    y[5] = static_cast<T>(-2)*(B[9]*x[1] - B[10]*x[0]);
+}
+// y = top half of B^T x (the bottom half is zero): Sym xw + n x xw + 2 l x xu
+template <typename T>
+__device__ __forceinline__ void grid_btmul(T (&y)[3], const T (&B)[12], const T (&x)[6]) {
+    y[0] = B[0]*x[0] + B[1]*x[1] + B[2]*x[2] + (B[7]*x[2] - B[8]*x[1]) + static_cast<T>(2)*(B[10]*x[5] - B[11]*x[4]);
+    y[1] = B[1]*x[0] + B[3]*x[1] + B[4]*x[2] + (B[8]*x[0] - B[6]*x[2]) + static_cast<T>(2)*(B[11]*x[3] - B[9]*x[5]);
+    y[2] = B[2]*x[0] + B[4]*x[1] + B[5]*x[2] + (B[6]*x[1] - B[7]*x[0]) + static_cast<T>(2)*(B[9]*x[4] - B[10]*x[3]);
+}
+"""
+
+
+def gen_tip_frame_library(self):
+    """Generic device helpers of the tip-frame path plus the lane-group scans (their step count depends on GRID_LANES_PER_SOLVE)."""
+    for line in _TIP_LIBRARY.strip("\n").split("\n"):
+        self.gen_add_code_line(line)
+    G = self.lanes_per_solve
+    steps = [k for k in (1, 2, 4, 8) if k < G]
+    ns = len(steps)
+    self.gen_add_code_line("")
+    self.gen_add_code_line("// inclusive sums over the lanes of one lane group (lane j <-> joint j of a serial chain): prefix = over joint j and its ancestors,")
+    self.gen_add_code_line("// suffix = over joint j and its descendants.  Log-step DPP scans; mk[s] is 1 where the partner lane of step s is in the same group.")
+    self.gen_add_code_line("#define GRID_SCAN_STEPS %d" % ns)
+    for name, fn, cmp_ in (("prefix", "grid_lane_below", "(lane & %d) >= %d"), ("suffix", "grid_lane_above", "(lane & %d) + %d < %d")):
+        self.gen_add_code_line("template <typename T>")
+        self.gen_add_code_line("__device__ __forceinline__ void grid_%s_masks(T (&mk)[GRID_SCAN_STEPS], const int lane) {" % name, True)
+        for s_, k in enumerate(steps):
+            cond = (cmp_ % (G - 1, k)) if name == "prefix" else (cmp_ % (G - 1, k, G))
+            self.gen_add_code_line("mk[%d] = (%s) ? static_cast<T>(1) : static_cast<T>(0);" % (s_, cond))
+        self.gen_add_end_function()
+        self.gen_add_code_line("template <int N, typename T>")
+        self.gen_add_code_line("__device__ __forceinline__ void grid_%s_sum(T (&x)[N], const T (&mk)[GRID_SCAN_STEPS]) {" % name, True)
+        for s_, k in enumerate(steps):
+            self.gen_add_code_line("#pragma unroll")
+            self.gen_add_code_line("for (int r = 0; r < N; r++) { x[r] += mk[%d]*%s<%d>(x[r]); }" % (s_, fn, k))
+        self.gen_add_end_function()
+    self.gen_add_code_line("")
+
+
+def _chain_step(self, i):
+    """Frame-chain step of joint i: keep (R_i, p_i) on lane i, then move the running frame to the parent of i (or, for the root,
+    read off the world's gravity direction).  Emitted inside the M^-1 backward sweep (same joint order)."""
+    m = self.model
+    E_nz = m.X_pattern[i][0]
+    r = self.gen_tip_frame_joint_offset(i)
+    C = lambda x: "static_cast<T>(" + repr(float(x)) + ")"
+    self.gen_add_code_line("{ // tip-frame chain, joint %d: lane %d keeps (R, p) of its own frame; then frame %d -> frame of its parent" % (i, i, i), True)
+    self.gen_add_code_line("#pragma unroll")
+    self.gen_add_code_line("for (int r = 0; r < 9; r++) { myR[r] = (lane == %d) ? Rc[r] : myR[r]; }" % i)
+    self.gen_add_code_line("#pragma unroll")
+    self.gen_add_code_line("for (int r = 0; r < 3; r++) { myp[r] = (lane == %d) ? pc[r] : myp[r]; }" % i)
+    self.gen_add_code_line("const T *Ei = &s_X[GRID_X_STRIDE*%d]; // E_%d(q): parent -> child coordinates (row-major)" % (i, i))
+    self.gen_add_code_line("T Rn[9];")
+    for rr in range(3):
+        for cc in range(3):
+            terms = ["Rc[%d]*Ei[%d]" % (3 * rr + k, 3 * k + cc) for k in range(3) if E_nz[k, cc]]
+            self.gen_add_code_line("Rn[%d] = %s;" % (3 * rr + cc, " + ".join(terms) if terms else "static_cast<T>(0)"))
+    if i > 0:
+        for rr in range(3):
+            terms = ["Rn[%d]*%s" % (3 * rr + k, C(r[k])) for k in range(3) if r[k] != 0.0]
+            if terms:
+                self.gen_add_code_line("pc[%d] -= %s;" % (rr, " + ".join(terms)))
+        self.gen_add_code_line("#pragma unroll")
+        self.gen_add_code_line("for (int r = 0; r < 9; r++) { Rc[r] = Rn[r]; }")
+    else:
+        self.gen_add_code_line("gvec[0] = gravity*Rn[2]; gvec[1] = gravity*Rn[5]; gvec[2] = gravity*Rn[8]; // base acceleration (0,0,g) in F coordinates")
+    self.gen_add_end_control_flow()
+
+
+def _emit_chain_decls(self):
+    self.gen_add_code_line("// running frame of the tip -> base chain (wave-uniform) and this lane's own frame: R maps link coordinates to F, p is the link origin in F")
+    self.gen_add_code_line("T Rc[9] = {static_cast<T>(1), static_cast<T>(0), static_cast<T>(0), static_cast<T>(0), static_cast<T>(1), static_cast<T>(0), static_cast<T>(0), static_cast<T>(0), static_cast<T>(1)};")
+    self.gen_add_code_line("T pc[3] = {static_cast<T>(0), static_cast<T>(0), static_cast<T>(0)};")
+    self.gen_add_code_line("T myR[9], myp[3], gvec[3];")
+    self.gen_add_code_line("#pragma unroll")
+    self.gen_add_code_line("for (int r = 0; r < 9; r++) { myR[r] = Rc[r]; }")
+    self.gen_add_code_line("#pragma unroll")
+    self.gen_add_code_line("for (int r = 0; r < 3; r++) { myp[r] = pc[r]; }")
+
+
+def _emit_link_setup(self):
+    """Per lane: joint axis S and link inertia in F coordinates; velocity prefix sum; Pd; bias acceleration (qdd = 0)."""
+    m = self.model
+    n = m.n
+    same_axis = len(set(m.S_index)) == 1
+    self.gen_add_code_line("//")
+    self.gen_add_code_line("// tip frame, lane j <-> joint j: joint axis, link inertia, velocity, bias acceleration / force, Coriolis matrix")
+    self.gen_add_code_line("//")
+    self.gen_add_code_line("T mku[GRID_SCAN_STEPS], mkd[GRID_SCAN_STEPS]; grid_prefix_masks(mku, lane); grid_suffix_masks(mkd, lane);")
+    self.gen_add_code_line("const T qd = s_qd[lane]; // (lanes without a joint read a neighbouring finite value: their inertia is zero and nothing reads their prefix sums)")
+    self.gen_add_code_line("T S[6];")
+    if same_axis:
+        a = m.S_index[0]
+        self.gen_add_code_line("S[0] = myR[%d]; S[1] = myR[%d]; S[2] = myR[%d]; // rotation axis %s of the link frame" % (a, 3 + a, 6 + a, "xyz"[a]))
+    else:
+        self.gen_add_code_line("{ const int ax = static_cast<int>(Lc[11]);")
+        self.gen_add_code_line("  #pragma unroll")
+        self.gen_add_code_line("  for (int r = 0; r < 3; r++) { S[r] = (ax == 0) ? myR[3*r] : ((ax == 1) ? myR[3*r+1] : myR[3*r+2]); } }")
+    self.gen_add_code_line("S[3] = myp[1]*S[2] - myp[2]*S[1]; S[4] = myp[2]*S[0] - myp[0]*S[2]; S[5] = myp[0]*S[1] - myp[1]*S[0];")
+    self.gen_add_code_line("T I[10]; // this link's inertia about the origin of F")
+    self.gen_add_code_line("{", True)
+    self.gen_add_code_line("T d[3], RI[9];")
+    self.gen_add_code_line("#pragma unroll")
+    self.gen_add_code_line("for (int r = 0; r < 3; r++) {", True)
+    self.gen_add_code_line("d[r] = myp[r] + myR[3*r]*Lc[6] + myR[3*r+1]*Lc[7] + myR[3*r+2]*Lc[8]; // centre of mass")
+    self.gen_add_code_line("RI[3*r]   = myR[3*r]*Lc[0] + myR[3*r+1]*Lc[1] + myR[3*r+2]*Lc[2];")
+    self.gen_add_code_line("RI[3*r+1] = myR[3*r]*Lc[1] + myR[3*r+1]*Lc[3] + myR[3*r+2]*Lc[4];")
+    self.gen_add_code_line("RI[3*r+2] = myR[3*r]*Lc[2] + myR[3*r+1]*Lc[4] + myR[3*r+2]*Lc[5];")
+    self.gen_add_end_control_flow()
+    self.gen_add_code_line("const T md0 = Lc[9]*d[0], md1 = Lc[9]*d[1], md2 = Lc[9]*d[2];")
+    for k, (r_, c_) in enumerate(((0, 0), (0, 1), (0, 2), (1, 1), (1, 2), (2, 2))):
+        rot = "RI[%d]*myR[%d] + RI[%d]*myR[%d] + RI[%d]*myR[%d]" % (3 * r_, 3 * c_, 3 * r_ + 1, 3 * c_ + 1, 3 * r_ + 2, 3 * c_ + 2)
+        if r_ == c_:
+            o1, o2 = [x for x in range(3) if x != r_]
+            self.gen_add_code_line("I[%d] = %s + md%d*d[%d] + md%d*d[%d];" % (k, rot, o1, o1, o2, o2))
+        else:
+            self.gen_add_code_line("I[%d] = %s - md%d*d[%d];" % (k, rot, r_, c_))
+    self.gen_add_code_line("I[6] = md0; I[7] = md1; I[8] = md2; I[9] = Lc[9];")
+    self.gen_add_end_control_flow()
+    self.gen_add_code_line("T v[6];")
+    self.gen_add_code_line("#pragma unroll")
+    self.gen_add_code_line("for (int r = 0; r < 6; r++) { v[r] = S[r]*qd; }")
+    self.gen_add_code_line("grid_prefix_sum<6>(v, mku); // v_j = sum over the ancestors of S_k qd_k")
+    self.gen_add_code_line("T Pd[6]; grid_mxm(Pd, v, S); // = S_j-dot")
+
+
+def _emit_bias(self, with_qdd):
+    """a (qdd = 0 or with qdd), Iv, f, Coriolis matrix and the composite (suffix) sums; leaves IC[10], BC[12], fC[6], a[6]."""
+    self.gen_add_code_line("T a[6];")
+    self.gen_add_code_line("#pragma unroll")
+    if with_qdd:
+        self.gen_add_code_line("for (int r = 0; r < 6; r++) { a[r] = Pd[r]*qd + S[r]*qdd; }")
+    else:
+        self.gen_add_code_line("for (int r = 0; r < 6; r++) { a[r] = Pd[r]*qd; }")
+    self.gen_add_code_line("grid_prefix_sum<6>(a, mku);")
+    self.gen_add_code_line("a[3] += gvec[0]; a[4] += gvec[1]; a[5] += gvec[2];")
+    self.gen_add_code_line("T IC[10], BC[12], fC[6];")
+    self.gen_add_code_line("{", True)
+    self.gen_add_code_line("T Iv[6]; grid_rbi_mul(Iv, I, v); // [n; l]: the link's momentum")
+    self.gen_add_code_line("grid_rbi_mul(fC, I, a); grid_fxv_peq(fC, v, Iv);")
+    self.gen_add_code_line("// Sym = A + A^T - h u^T - u h^T + 2 (u.h) 1  with  A = w~ Ibar")
+    self.gen_add_code_line("const T A00 = v[1]*I[2] - v[2]*I[1], A01 = v[1]*I[4] - v[2]*I[3], A02 = v[1]*I[5] - v[2]*I[4];")
+    self.gen_add_code_line("const T A10 = v[2]*I[0] - v[0]*I[2], A11 = v[2]*I[1] - v[0]*I[4], A12 = v[2]*I[2] - v[0]*I[5];")
+    self.gen_add_code_line("const T A20 = v[0]*I[1] - v[1]*I[0], A21 = v[0]*I[3] - v[1]*I[1], A22 = v[0]*I[4] - v[1]*I[2];")
+    self.gen_add_code_line("const T uh = static_cast<T>(2)*(v[3]*I[6] + v[4]*I[7] + v[5]*I[8]);")
+    self.gen_add_code_line("BC[0] = static_cast<T>(2)*(A00 - I[6]*v[3]) + uh;")
+    self.gen_add_code_line("BC[1] = A01 + A10 - I[6]*v[4] - I[7]*v[3];")
+    self.gen_add_code_line("BC[2] = A02 + A20 - I[6]*v[5] - I[8]*v[3];")
+    self.gen_add_code_line("BC[3] = static_cast<T>(2)*(A11 - I[7]*v[4]) + uh;")
+    self.gen_add_code_line("BC[4] = A12 + A21 - I[7]*v[5] - I[8]*v[4];")
+    self.gen_add_code_line("BC[5] = static_cast<T>(2)*(A22 - I[8]*v[5]) + uh;")
+    self.gen_add_code_line("#pragma unroll")
+    self.gen_add_code_line("for (int r = 0; r < 6; r++) { BC[6 + r] = Iv[r]; }")
+    self.gen_add_end_control_flow()
+    self.gen_add_code_line("#pragma unroll")
+    self.gen_add_code_line("for (int r = 0; r < 10; r++) { IC[r] = I[r]; }")
+    self.gen_add_code_line("grid_suffix_sum<10>(IC, mkd); grid_suffix_sum<12>(BC, mkd); grid_suffix_sum<6>(fC, mkd); // composites over the links j..n-1")
+
+
+def _emit_assembly(self, s_G="s_G", dst="s_df_du", minv="s_Minv"):
+    """Pdd, t1..t4, the [S | t1 | t4] hand-off and this lane's two columns of dc/du, then -Minv*dc/du into the staging area."""
+    m = self.model
+    n = m.n
+    ld = self.minv_ld
+    self.gen_add_code_line("T Pdd[6]; grid_mxm(Pdd, a, S); grid_mxm_peq(Pdd, v, Pd);")
+    self.gen_add_code_line("T t1[6], t2[6], t3[6], t4[3];")
+    self.gen_add_code_line("grid_rbi_mul(t1, IC, S);")
+    self.gen_add_code_line("grid_bmul(t2, BC, S); grid_rbi_mul_peq(t2, IC, Pd, static_cast<T>(2));")
+    self.gen_add_code_line("grid_bmul(t3, BC, Pd); grid_rbi_mul_peq(t3, IC, Pdd, static_cast<T>(1)); grid_fxv_peq(t3, S, fC);")
+    self.gen_add_code_line("grid_btmul(t4, BC, S);")
+    self.gen_add_code_line("if (lane < %d) { // hand-off record of joint `lane`: [S | t1 | t4]" % n, True)
+    self.gen_add_code_line("T *rec = &%s[16*lane];" % s_G)
+    self.gen_add_code_line("#pragma unroll")
+    self.gen_add_code_line("for (int r = 0; r < 6; r++) { rec[r] = S[r]; rec[6 + r] = t1[r]; }")
+    self.gen_add_code_line("rec[12] = t4[0]; rec[13] = t4[1]; rec[14] = t4[2]; rec[15] = static_cast<T>(0);")
+    self.gen_add_end_control_flow()
+    self.gen_add_sync(False)
+    self.gen_add_code_line("// column `lane` of dc/dq and of dc/dqd: rows k <= lane use this lane's t3, t2 with S_k; rows k > lane use t1_k, t4_k with this lane's Pdd, Pd, S")
+    self.gen_add_code_line("T dq[%d], dqd[%d];" % (n, n))
+    self.gen_add_code_line("#pragma unroll")
+    self.gen_add_code_line("for (int k = 0; k < %d; k++) {" % n, True)
+    self.gen_add_code_line("T g[16];")
+    self.gen_add_code_line("#pragma unroll")
+    self.gen_add_code_line("for (int r = 0; r < 16; r++) { g[r] = %s[16*k + r]; }" % s_G)
+    self.gen_add_code_line("const T up_q = g[0]*t3[0] + g[1]*t3[1] + g[2]*t3[2] + g[3]*t3[3] + g[4]*t3[4] + g[5]*t3[5];")
+    self.gen_add_code_line("const T up_d = g[0]*t2[0] + g[1]*t2[1] + g[2]*t2[2] + g[3]*t2[3] + g[4]*t2[4] + g[5]*t2[5];")
+    self.gen_add_code_line("const T lo_q = g[6]*Pdd[0] + g[7]*Pdd[1] + g[8]*Pdd[2] + g[9]*Pdd[3] + g[10]*Pdd[4] + g[11]*Pdd[5] + g[12]*Pd[0] + g[13]*Pd[1] + g[14]*Pd[2];")
+    self.gen_add_code_line("const T lo_d = static_cast<T>(2)*(g[6]*Pd[0] + g[7]*Pd[1] + g[8]*Pd[2] + g[9]*Pd[3] + g[10]*Pd[4] + g[11]*Pd[5]) + g[12]*S[0] + g[13]*S[1] + g[14]*S[2];")
+    self.gen_add_code_line("dq[k] = (k <= lane) ? up_q : lo_q;")
+    self.gen_add_code_line("dqd[k] = ((k <= lane) ? up_d : lo_d) + ((k == lane) ? Lc[10] : static_cast<T>(0)); // + damping on the diagonal (oracle _test.py:486)")
+    self.gen_add_end_control_flow()
+    if minv is None:
+        self.gen_add_code_line("if (lane < %d) {" % n, True)
+        self.gen_add_code_line("#pragma unroll")
+        self.gen_add_code_line("for (int row = 0; row < %d; row++) { %s[lane*%d + row] = dq[row]; %s[(%d + lane)*%d + row] = dqd[row]; }" % (n, dst, n, dst, n, n))
+        self.gen_add_end_control_flow()
+        return
+    self.gen_add_code_line("// finally df/du = -Minv*dc/du for the two columns this lane owns (Minv is read wave-uniformly from LDS)")
+    self.gen_add_code_line("if (lane < %d) {" % n, True)
+    self.gen_add_code_line("#pragma unroll")
+    self.gen_add_code_line("for (int row = 0; row < %d; row++) {" % n, True)
+    self.gen_add_code_line("T vq = static_cast<T>(0), vd = static_cast<T>(0);")
+    self.gen_add_code_line("#pragma unroll")
+    self.gen_add_code_line("for (int i = 0; i < %d; i++) { const T mi = %s[row*%d + i]; vq += mi*dq[i]; vd += mi*dqd[i]; }" % (n, minv, ld))
+    self.gen_add_code_line("%s[lane*%d + row] = -vq; %s[(%d + lane)*%d + row] = -vd;" % (dst, n, dst, n, n))
+    self.gen_add_end_control_flow()
+    self.gen_add_end_control_flow()
+
+
+def _emit_link_constants_load(self):
+    n = self.model.n
+    self.gen_add_code_line("T Lc[12]; // this lane's link constants: Ic (6, about the centre of mass), c (3), m, damping, axis")
+    self.gen_add_code_line("{ const T *d_L = &grid_model_constants(static_cast<const T *>(nullptr))[%d + 12*lane]; (void)d_robotModel;" % (54 * n))
+    self.gen_add_code_line("  #pragma unroll")
+    self.gen_add_code_line("  for (int r = 0; r < 12; r++) { Lc[r] = d_L[r]; } }")
+
+
+def gen_forward_dynamics_gradient_inner_tip(self, use_thread_group=False, use_qdd_Minv_input=False):
+    """The fused inner of the tip-frame path.  u-input form: M^-1 (Carpentier, link-local frames, unchanged) with the frame chain inside
+    its backward sweep, bias force in F, qdd, then the assembly.  (qdd, Minv)-input form: chain, setup and assembly only."""
+    m = self.model
+    n = m.n
+    name = "forward_dynamics_gradient_inner_tip" + ("_qdd_minv" if use_qdd_Minv_input else "")
+    notes = ["serial revolute chains only; all link quantities are expressed in the frame of the tip link (see the module notes of",
+             "algorithms/_tip_frame_gradient.py); same results as direct_minv_inner + inverse_dynamics_inner + inverse_dynamics_gradient_inner",
+             "s_df_du receives -Minv*dc/du in the device layout [col*n + row]; the caller must grid_wave_sync() before other lanes read it"]
+    params = ["s_df_du is a pointer to LDS for the final result of size 2*NUM_JOINTS*NUM_JOINTS = " + str(2 * n * n),
+              "s_qd is the vector of joint velocities in LDS"]
+    if use_qdd_Minv_input:
+        params += ["s_qdd is the vector of joint accelerations in LDS", "s_Minv is the dense symmetric inverse mass matrix in LDS (leading dimension GRID_MINV_LD)",
+                   "s_X is this solve's compact X(q) storage; it is overwritten by the per-joint hand-off records"]
+        sig = "T *s_df_du, const T *s_qd, const T *s_qdd, const T *s_Minv, T *s_X, const robotModel<T> *d_robotModel, const T gravity, const int lane"
+    else:
+        params += ["s_u is the vector of joint input torques in LDS", "s_X is this solve's compact X(q) storage; it is overwritten by the per-joint hand-off records",
+                   "s_U, s_T are LDS scratch (see direct_minv_inner)", "s_Minv receives the dense inverse mass matrix", "s_qdd is LDS scratch for tau - c (NUM_JOINTS values)"]
+        sig = "T *s_df_du, const T *s_qd, const T *s_u, T *s_X, T *s_U, T *s_T, T *s_Minv, T *s_qdd, const robotModel<T> *d_robotModel, const T gravity, const int lane"
+    params += ["d_robotModel is the pointer to the initialized model specific helpers on the GPU", "gravity is the gravity constant",
+               "lane is the caller's lane index inside the solve's lane group"]
+    self.gen_add_func_doc("Computes the gradient of forward dynamics in the tip frame", notes, params, None)
+    self.gen_add_code_line("template <typename T>")
+    self.gen_add_code_line("__device__ __forceinline__")
+    self.gen_add_code_line("void %s(%s) {" % (name, sig), True)
+    _emit_link_constants_load(self)
+    _emit_chain_decls(self)
+    if use_qdd_Minv_input:
+        for i in range(n - 1, -1, -1):
+            _chain_step(self, i)
+        self.gen_add_sync(use_thread_group)  # every lane is done with s_X before the hand-off records overwrite it
+        _emit_link_setup(self)
+        self.gen_add_code_line("const T qdd = s_qdd[lane];")
+        _emit_bias(self, True)
+        _emit_assembly(self, s_G="s_X")
+        self.gen_add_end_function()
+        return
+
+    def bwd_hook(idx):
+        _chain_step(self, n - 1 - idx)
+
+    def fwd_hook():
+        _emit_link_setup(self)
+        _emit_bias(self, False)
+        self.gen_add_code_line("// bias force of this lane's joint and its share of tau - c")
+        self.gen_add_code_line("const T cj = grid_dot6(S, fC) + Lc[10]*qd;")
+        self.gen_add_code_line("if (lane < %d) { s_qdd[lane] = s_u[lane] - cj; }" % n)
+
+    self.gen_direct_minv_inner(use_thread_group, body_only=True, bwd_hook=bwd_hook, fwd_hook=fwd_hook)
+    self.gen_add_sync(use_thread_group)
+    self.gen_add_code_line("// qdd_j = Minv[j,:] (tau - c); then the acceleration-dependent parts: a += sum over the ancestors of S_k qdd_k, f^C += sum over the subtree of I_k da_k")
+    self.gen_add_code_line("T qdd = static_cast<T>(0);")
+    self.gen_add_code_line("#pragma unroll")
+    self.gen_add_code_line("for (int col = 0; col < %d; col++) { qdd += s_Minv[lane*%d + col]*s_qdd[col]; }" % (n, self.minv_ld))
+    self.gen_add_code_line("qdd = (lane < %d) ? qdd : static_cast<T>(0);" % n)
+    self.gen_add_code_line("{", True)
+    self.gen_add_code_line("T da[6], Ida[6];")
+    self.gen_add_code_line("#pragma unroll")
+    self.gen_add_code_line("for (int r = 0; r < 6; r++) { da[r] = S[r]*qdd; }")
+    self.gen_add_code_line("grid_prefix_sum<6>(da, mku);")
+    self.gen_add_code_line("grid_rbi_mul(Ida, I, da); grid_suffix_sum<6>(Ida, mkd);")
+    self.gen_add_code_line("#pragma unroll")
+    self.gen_add_code_line("for (int r = 0; r < 6; r++) { a[r] += da[r]; fC[r] += Ida[r]; }")
+    self.gen_add_end_control_flow()
+    if self.DEBUG_MODE:
+        self.gen_add_sync(use_thread_group)
+        self.gen_add_code_line("if (lane < %d) { s_qdd[lane] = qdd; } // DEBUG_MODE prints qdd" % n)
+    _emit_assembly(self, s_G="s_X")
+    self.gen_add_end_function()
+
+
+def gen_forward_dynamics_gradient_inner_tip_function_call(self, use_thread_group=False, use_qdd_Minv_input=False, s_df_du_name="s_df_du"):
+    if use_qdd_Minv_input:
+        self.gen_add_code_line("forward_dynamics_gradient_inner_tip_qdd_minv<T>(%s, s_qd, s_qdd, s_Minv, s_X, d_robotModel, gravity, lane);" % s_df_du_name)
+    else:
+        self.gen_add_code_line("forward_dynamics_gradient_inner_tip<T>(%s, s_qd, s_u, s_X, s_U, s_T, s_Minv, s_qdd, d_robotModel, gravity, lane);" % s_df_du_name)
+
+
+def gen_tip_frame_gradient(self, use_thread_group=False):
+    self.gen_forward_dynamics_gradient_inner_tip(use_thread_group, False)
+    self.gen_forward_dynamics_gradient_inner_tip(use_thread_group, True)

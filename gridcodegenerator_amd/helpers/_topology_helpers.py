@@ -64,6 +64,8 @@ def gen_model_constant_table(self):
         vals += [XT[r, c] for r in range(3) for c in range(3)] + [XT[3 + r, c] for r in range(3) for c in range(3)]
     for i in range(n):
         vals += [m.I[i][row, col] for col in range(6) for row in range(6)]
+    if getattr(self, "tip_frame", False):  # one 12-float row of link constants per lane of the lane group (tip-frame gradient path)
+        vals += self.gen_tip_frame_link_constants()
     for ctype, sfx in (("float", "f"), ("double", "")):
         self.gen_add_code_line("__device__ const %s grid_model_constants_%s[%d] = {" % (ctype, ctype, len(vals)), True)
         for k in range(0, len(vals), 6):

@@ -96,6 +96,25 @@ inline float shfl(float v, int src, int width) {
 }
 }  // namespace hipemu
 #define __shfl(v, src, width) hipemu::shfl((v), (src), (width))
+// DPP row shifts (row_shr:K = 0x110+K reads lane-K, row_shl:K = 0x100+K reads lane+K, inside rows of 16 consecutive lanes); a source
+// outside the row yields 0 with bound_ctrl, else `old`.  Only what the generated code uses (full row/bank masks).
+namespace hipemu {
+inline int g_dpp[1024];
+inline int update_dpp(int old, int src, int ctrl, int row_mask, int bank_mask, bool bound_ctrl) {
+    if (row_mask != 0xf || bank_mask != 0xf) { fprintf(stderr, "hipemu: DPP row/bank masks are not emulated\n"); abort(); }
+    const unsigned t = threadIdx.x + threadIdx.y * blockDim.x;
+    g_dpp[t] = src;
+    wave_barrier();
+    int from;
+    if (ctrl >= 0x111 && ctrl <= 0x11f) from = (int)(t & 15u) - (ctrl - 0x110);
+    else if (ctrl >= 0x101 && ctrl <= 0x10f) from = (int)(t & 15u) + (ctrl - 0x100);
+    else { fprintf(stderr, "hipemu: DPP control 0x%x is not emulated\n", ctrl); abort(); }
+    const int r = (from >= 0 && from < 16) ? g_dpp[(t & ~15u) + (unsigned)from] : (bound_ctrl ? 0 : old);
+    wave_barrier();
+    return r;
+}
+}  // namespace hipemu
+#define __builtin_amdgcn_update_dpp(old, src, ctrl, rm, bm, bc) hipemu::update_dpp((old), (src), (ctrl), (rm), (bm), (bc))
 #define __builtin_amdgcn_fence(...) ((void)0)
 #define __builtin_amdgcn_wave_barrier() hipemu::wave_barrier()
 #define hipLaunchKernelGGL(kernel, grid, block, smem, stream, ...) hipemu::launch((grid), (block), (smem), [&]() { kernel(__VA_ARGS__); })
