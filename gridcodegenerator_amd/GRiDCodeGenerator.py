@@ -86,7 +86,7 @@ class GRiDCodeGenerator:
         tip_ok = (all(m_.parent[j] == j - 1 for j in range(n)) and all(s_ < 3 for s_ in m_.S_index) and COLS_PER_LANE == 2 and lanes <= 16)
         if mode == "tipframe" and not tip_ok:
             raise NotImplementedError("GRID_GRADIENT_WALK=tipframe needs a serial chain of revolute joints with at most 16 joints")
-        self.tip_frame = tip_ok and mode in ("auto", "tipframe")
+        self.tip_frame = tip_ok and mode in ("auto", "tipframe") and not DEBUG_MODE  # (DEBUG_MODE prints M^-1, which this path never forms)
         self.reuse_rnea = self.register_walk and n <= 9 and _os.environ.get("GRID_FUSE_FD", "1") == "1" and _os.environ.get("GRID_REUSE_RNEA", "0") == "1"  # measured: 16.6 us vs 15.0 us per launch with re-use (extra LDS traffic on the critical path), so off by default
         # tuning knob: minimum waves per SIMD the register allocator must leave room for (second __launch_bounds__ argument); 0 = compiler's choice
         self.min_waves_per_eu = int(__import__("os").environ.get("GRID_MIN_WAVES", "0"))

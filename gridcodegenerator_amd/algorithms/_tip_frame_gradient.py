@@ -343,9 +343,36 @@ def _emit_link_constants_load(self):
     self.gen_add_code_line("  for (int r = 0; r < 12; r++) { Lc[r] = d_L[r]; } }")
 
 
+def _emit_ldl_factor(self, A="A", U="Uf", rd="rd"):
+    """In-register U D U^T factorisation of the symmetric n x n matrix A (upper triangle A[i][j], i <= j), eliminating the tip joint
+    first: A = Uf diag(1/rd) Uf^T with Uf unit upper triangular.  Wave-uniform (every lane factors the same matrix): n reciprocals,
+    n(n-1)/2 multiplies, (n-1)n(n+1)/6 FMAs and no cross-lane traffic.  Diagonal scaling does not affect an unpivoted symmetric
+    factorisation, so the badly scaled joint-space inertia (1e-3 at the wrist, 10 at the base) is harmless."""
+    n = self.model.n
+    for k in range(n - 1, 0, -1):
+        self.gen_add_code_line("const T %s%d = grid_rcp(%s%d_%d);" % (rd, k, A, k, k))
+        self.gen_add_code_line(" ".join("const T %s%d_%d = %s%d_%d*%s%d;" % (U, i, k, A, i, k, rd, k) for i in range(k)))
+        for j in range(k):
+            self.gen_add_code_line(" ".join("%s%d_%d -= %s%d_%d*%s%d_%d;" % (A, i, j, U, i, k, A, j, k) for i in range(j + 1)))
+    self.gen_add_code_line("const T %s0 = grid_rcp(%s0_0);" % (rd, A))
+
+
+def _emit_ldl_solve(self, b, U="Uf", rd="rd"):
+    """b <- A^-1 b for the register vector b[n] with the factors of _emit_ldl_factor: Uf y = b, z = y/D, Uf^T x = z."""
+    n = self.model.n
+    for k in range(n - 1, 0, -1):
+        self.gen_add_code_line(" ".join("%s[%d] -= %s%d_%d*%s[%d];" % (b, i, U, i, k, b, k) for i in range(k)))
+    self.gen_add_code_line(" ".join("%s[%d] *= %s%d;" % (b, k, rd, k) for k in range(n)))
+    for k in range(1, n):
+        self.gen_add_code_line("%s[%d] -= %s;" % (b, k, " + ".join("%s%d_%d*%s[%d]" % (U, i, k, b, i) for i in range(k))))
+
+
 def gen_forward_dynamics_gradient_inner_tip(self, use_thread_group=False, use_qdd_Minv_input=False):
-    """The fused inner of the tip-frame path.  u-input form: M^-1 (Carpentier, link-local frames, unchanged) with the frame chain inside
-    its backward sweep, bias force in F, qdd, then the assembly.  (qdd, Minv)-input form: chain, setup and assembly only."""
+    """The fused inner of the tip-frame path.
+    (qdd, Minv)-input form: frame chain, link setup, assembly of dc/du, product with the caller's M^-1.
+    u-input form: additionally the joint-space inertia itself comes from the tip-frame composites, M[k][j] = S_k . (I^C_j S_j) for k <= j,
+    and is never inverted: every lane factors it (U D U^T, wave-uniform registers) and solves for tau - c and for its own two columns
+    of dc/du.  No link-local transforms, no articulated inertias, no M^-1 sweeps."""
     m = self.model
     n = m.n
     name = "forward_dynamics_gradient_inner_tip" + ("_qdd_minv" if use_qdd_Minv_input else "")
@@ -359,9 +386,9 @@ def gen_forward_dynamics_gradient_inner_tip(self, use_thread_group=False, use_qd
                    "s_X is this solve's compact X(q) storage; it is overwritten by the per-joint hand-off records"]
         sig = "T *s_df_du, const T *s_qd, const T *s_qdd, const T *s_Minv, T *s_X, const robotModel<T> *d_robotModel, const T gravity, const int lane"
     else:
-        params += ["s_u is the vector of joint input torques in LDS", "s_X is this solve's compact X(q) storage; it is overwritten by the per-joint hand-off records",
-                   "s_U, s_T are LDS scratch (see direct_minv_inner)", "s_Minv receives the dense inverse mass matrix", "s_qdd is LDS scratch for tau - c (NUM_JOINTS values)"]
-        sig = "T *s_df_du, const T *s_qd, const T *s_u, T *s_X, T *s_U, T *s_T, T *s_Minv, T *s_qdd, const robotModel<T> *d_robotModel, const T gravity, const int lane"
+        params += ["s_u is the vector of joint input torques in LDS", "s_X is this solve's compact X(q) storage (only the rotation blocks are read)",
+                   "s_G is LDS scratch for the per-joint hand-off records (16 values per joint)", "s_M is LDS scratch for the joint-space inertia matrix (leading dimension GRID_MINV_LD)"]
+        sig = "T *s_df_du, const T *s_qd, const T *s_u, const T *s_X, T *s_G, T *s_M, const robotModel<T> *d_robotModel, const T gravity, const int lane"
     params += ["d_robotModel is the pointer to the initialized model specific helpers on the GPU", "gravity is the gravity constant",
                "lane is the caller's lane index inside the solve's lane group"]
     self.gen_add_func_doc("Computes the gradient of forward dynamics in the tip frame", notes, params, None)
@@ -370,9 +397,9 @@ def gen_forward_dynamics_gradient_inner_tip(self, use_thread_group=False, use_qd
     self.gen_add_code_line("void %s(%s) {" % (name, sig), True)
     _emit_link_constants_load(self)
     _emit_chain_decls(self)
+    for i in range(n - 1, -1, -1):
+        _chain_step(self, i)
     if use_qdd_Minv_input:
-        for i in range(n - 1, -1, -1):
-            _chain_step(self, i)
         self.gen_add_sync(use_thread_group)  # every lane is done with s_X before the hand-off records overwrite it
         _emit_link_setup(self)
         self.gen_add_code_line("const T qdd = s_qdd[lane];")
@@ -380,24 +407,69 @@ def gen_forward_dynamics_gradient_inner_tip(self, use_thread_group=False, use_qd
         _emit_assembly(self, s_G="s_X")
         self.gen_add_end_function()
         return
-
-    def bwd_hook(idx):
-        _chain_step(self, n - 1 - idx)
-
-    def fwd_hook():
-        _emit_link_setup(self)
-        _emit_bias(self, False)
-        self.gen_add_code_line("// bias force of this lane's joint and its share of tau - c")
-        self.gen_add_code_line("const T cj = grid_dot6(S, fC) + Lc[10]*qd;")
-        self.gen_add_code_line("if (lane < %d) { s_qdd[lane] = s_u[lane] - cj; }" % n)
-
-    self.gen_direct_minv_inner(use_thread_group, body_only=True, bwd_hook=bwd_hook, fwd_hook=fwd_hook)
-    self.gen_add_sync(use_thread_group)
-    self.gen_add_code_line("// qdd_j = Minv[j,:] (tau - c); then the acceleration-dependent parts: a += sum over the ancestors of S_k qdd_k, f^C += sum over the subtree of I_k da_k")
-    self.gen_add_code_line("T qdd = static_cast<T>(0);")
+    import os
+    stop = int(os.environ.get("GRID_DEBUG_STOP", "0"))  # timing ablation only (results are wrong when set): 5 = chain, 6 = + link setup/bias/record, 7 = + M, factorisation, qdd
+    ld = self.minv_ld
+    if stop == 5:
+        self.gen_add_code_line("if (lane < %d) { s_df_du[lane] = myR[0] + myp[0] + gvec[0] + Lc[0]; }" % n)
+        self.gen_add_end_function()
+        return
+    _emit_link_setup(self)
+    _emit_bias(self, False)
+    self.gen_add_code_line("// everything that does not depend on qdd: t1, t2, t4, the bias force; one hand-off record per joint: [S | t1 | t4 | tau - c]")
+    self.gen_add_code_line("T t1[6], t2[6], t4[3];")
+    self.gen_add_code_line("grid_rbi_mul(t1, IC, S);")
+    self.gen_add_code_line("grid_bmul(t2, BC, S); grid_rbi_mul_peq(t2, IC, Pd, static_cast<T>(2));")
+    self.gen_add_code_line("grid_btmul(t4, BC, S);")
+    self.gen_add_code_line("if (lane < %d) {" % n, True)
+    self.gen_add_code_line("T *rec = &s_G[16*lane];")
     self.gen_add_code_line("#pragma unroll")
-    self.gen_add_code_line("for (int col = 0; col < %d; col++) { qdd += s_Minv[lane*%d + col]*s_qdd[col]; }" % (n, self.minv_ld))
-    self.gen_add_code_line("qdd = (lane < %d) ? qdd : static_cast<T>(0);" % n)
+    self.gen_add_code_line("for (int r = 0; r < 6; r++) { rec[r] = S[r]; rec[6 + r] = t1[r]; }")
+    self.gen_add_code_line("rec[12] = t4[0]; rec[13] = t4[1]; rec[14] = t4[2]; rec[15] = s_u[lane] - (grid_dot6(S, fC) + Lc[10]*qd);")
+    self.gen_add_end_control_flow()
+    self.gen_add_sync(use_thread_group)
+    if stop == 6:
+        self.gen_add_code_line("if (lane < %d) { s_df_du[lane] = s_G[16*lane + 15] + t2[0] + t2[1] + t2[2] + t2[3] + t2[4] + t2[5]; }" % n)
+        self.gen_add_end_function()
+        return
+    self.gen_add_code_line("// pass 1 over the records: column `lane` of M (rows k <= lane), column `lane` of dc/dqd (complete: it does not depend on qdd),")
+    self.gen_add_code_line("// the qdd-independent part of the rows k > lane of dc/dq, and tau - c of every joint")
+    self.gen_add_code_line("T dq[%d], dqd[%d], rhs[%d], Mcol[%d];" % (n, n, n, ld))
+    for k in range(n, ld):
+        self.gen_add_code_line("Mcol[%d] = static_cast<T>(0);" % k)
+    self.gen_add_code_line("#pragma unroll")
+    self.gen_add_code_line("for (int k = 0; k < %d; k++) {" % n, True)
+    self.gen_add_code_line("T g[16];")
+    self.gen_add_code_line("#pragma unroll")
+    self.gen_add_code_line("for (int r = 0; r < 16; r++) { g[r] = s_G[16*k + r]; }")
+    self.gen_add_code_line("const T mkj  = g[0]*t1[0] + g[1]*t1[1] + g[2]*t1[2] + g[3]*t1[3] + g[4]*t1[4] + g[5]*t1[5];")
+    self.gen_add_code_line("const T up_d = g[0]*t2[0] + g[1]*t2[1] + g[2]*t2[2] + g[3]*t2[3] + g[4]*t2[4] + g[5]*t2[5];")
+    self.gen_add_code_line("const T lo_d = static_cast<T>(2)*(g[6]*Pd[0] + g[7]*Pd[1] + g[8]*Pd[2] + g[9]*Pd[3] + g[10]*Pd[4] + g[11]*Pd[5]) + g[12]*S[0] + g[13]*S[1] + g[14]*S[2];")
+    self.gen_add_code_line("dq[k] = g[12]*Pd[0] + g[13]*Pd[1] + g[14]*Pd[2];")
+    self.gen_add_code_line("dqd[k] = ((k <= lane) ? up_d : lo_d) + ((k == lane) ? Lc[10] : static_cast<T>(0)); // + damping on the diagonal (oracle _test.py:486)")
+    self.gen_add_code_line("rhs[k] = g[15];")
+    self.gen_add_code_line("Mcol[k] = mkj; // (rows k > lane are never read)")
+    self.gen_add_end_control_flow()
+    self.gen_add_code_line("if (lane < %d) {" % n, True)
+    self.gen_add_code_line("#pragma unroll")
+    self.gen_add_code_line("for (int k = 0; k < %d; k++) { s_M[%d*lane + k] = Mcol[k]; }" % (ld, ld))
+    self.gen_add_end_control_flow()
+    self.gen_add_sync(use_thread_group)
+    self.gen_add_code_line("// the joint-space inertia, wave-uniform: upper triangle A<i>_<j> = M[i][j], i <= j  (column j was written by lane j)")
+    for j in range(n):
+        self.gen_add_code_line(" ".join("T A%d_%d = s_M[%d];" % (i, j, ld * j + i) for i in range(j + 1)))
+    _emit_ldl_factor(self)
+    self.gen_add_code_line("// qdd = M^-1 (tau - c); this lane keeps the entry of its own joint")
+    _emit_ldl_solve(self, "rhs")
+    sel = "rhs[0]"
+    for k in range(1, n):
+        sel = "((lane == %d) ? rhs[%d] : %s)" % (k, k, sel)
+    self.gen_add_code_line("const T qdd = (lane < %d) ? %s : static_cast<T>(0);" % (n, sel))
+    if stop == 7:
+        self.gen_add_code_line("if (lane < %d) { s_df_du[lane] = qdd + %s; }" % (n, " + ".join("dq[%d] + dqd[%d]" % (k, k) for k in range(n))))
+        self.gen_add_end_function()
+        return
+    self.gen_add_code_line("// the acceleration-dependent parts: a += sum over the ancestors of S_k qdd_k, f^C += sum over the subtree of I_k da_k")
     self.gen_add_code_line("{", True)
     self.gen_add_code_line("T da[6], Ida[6];")
     self.gen_add_code_line("#pragma unroll")
@@ -407,10 +479,25 @@ def gen_forward_dynamics_gradient_inner_tip(self, use_thread_group=False, use_qd
     self.gen_add_code_line("#pragma unroll")
     self.gen_add_code_line("for (int r = 0; r < 6; r++) { a[r] += da[r]; fC[r] += Ida[r]; }")
     self.gen_add_end_control_flow()
-    if self.DEBUG_MODE:
-        self.gen_add_sync(use_thread_group)
-        self.gen_add_code_line("if (lane < %d) { s_qdd[lane] = qdd; } // DEBUG_MODE prints qdd" % n)
-    _emit_assembly(self, s_G="s_X")
+    self.gen_add_code_line("T Pdd[6]; grid_mxm(Pdd, a, S); grid_mxm_peq(Pdd, v, Pd);")
+    self.gen_add_code_line("T t3[6]; grid_bmul(t3, BC, Pd); grid_rbi_mul_peq(t3, IC, Pdd, static_cast<T>(1)); grid_fxv_peq(t3, S, fC);")
+    self.gen_add_code_line("// pass 2 over the records: column `lane` of dc/dq")
+    self.gen_add_code_line("#pragma unroll")
+    self.gen_add_code_line("for (int k = 0; k < %d; k++) {" % n, True)
+    self.gen_add_code_line("T g[12];")
+    self.gen_add_code_line("#pragma unroll")
+    self.gen_add_code_line("for (int r = 0; r < 12; r++) { g[r] = s_G[16*k + r]; }")
+    self.gen_add_code_line("const T up_q = g[0]*t3[0] + g[1]*t3[1] + g[2]*t3[2] + g[3]*t3[3] + g[4]*t3[4] + g[5]*t3[5];")
+    self.gen_add_code_line("const T lo_q = g[6]*Pdd[0] + g[7]*Pdd[1] + g[8]*Pdd[2] + g[9]*Pdd[3] + g[10]*Pdd[4] + g[11]*Pdd[5] + dq[k];")
+    self.gen_add_code_line("dq[k] = (k <= lane) ? up_q : lo_q;")
+    self.gen_add_end_control_flow()
+    self.gen_add_code_line("// df/du = -M^-1 dc/du for the two columns this lane owns")
+    _emit_ldl_solve(self, "dq")
+    _emit_ldl_solve(self, "dqd")
+    self.gen_add_code_line("if (lane < %d) {" % n, True)
+    self.gen_add_code_line("#pragma unroll")
+    self.gen_add_code_line("for (int row = 0; row < %d; row++) { s_df_du[lane*%d + row] = -dq[row]; s_df_du[(%d + lane)*%d + row] = -dqd[row]; }" % (n, n, n, n))
+    self.gen_add_end_control_flow()
     self.gen_add_end_function()
 
 
@@ -418,7 +505,7 @@ def gen_forward_dynamics_gradient_inner_tip_function_call(self, use_thread_group
     if use_qdd_Minv_input:
         self.gen_add_code_line("forward_dynamics_gradient_inner_tip_qdd_minv<T>(%s, s_qd, s_qdd, s_Minv, s_X, d_robotModel, gravity, lane);" % s_df_du_name)
     else:
-        self.gen_add_code_line("forward_dynamics_gradient_inner_tip<T>(%s, s_qd, s_u, s_X, s_U, s_T, s_Minv, s_qdd, d_robotModel, gravity, lane);" % s_df_du_name)
+        self.gen_add_code_line("forward_dynamics_gradient_inner_tip<T>(%s, s_qd, s_u, s_X, s_U, s_Minv, d_robotModel, gravity, lane); // hand-off records in the U|T scratch, M in the M^-1 slot" % s_df_du_name)
 
 
 def gen_tip_frame_gradient(self, use_thread_group=False):

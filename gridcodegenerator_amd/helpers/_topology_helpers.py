@@ -25,10 +25,13 @@ def gen_lds_layout(self):
     n = self.model.n
     off = {}
     cur = 0
+    t_size = 80
+    if getattr(self, "tip_frame", False):  # the tip-frame path keeps 16 values per joint in the U|T scratch (M goes into the M^-1 slot)
+        t_size = max(t_size, _pad4(16 * n - (_pad4(18 * n) if self.reuse_rnea else 8 * n)))
     for name, size in (("IN", _pad4(4 * n)),          # q | qd | u  (| spare: qdd input for the qdd/Minv overloads)
                        ("X", 20 * n),                 # compact X(q): 18 of every 20
                        ("U", _pad4(18 * n) if self.reuse_rnea else 8 * n),  # U_i (6), 1/D_i, pad (deep/large robots); or v, I v, fx(v) I v of RNEA(qdd=0) kept for the gradient walk
-                       ("T", 80),                     # 6x6 transpose scratch (row stride 6, 40 per buffer), double buffered by tree-depth parity
+                       ("T", t_size),                 # 6x6 transpose scratch (row stride 6, 40 per buffer), double buffered by tree-depth parity
                        ("MINV", n * _pad4(n)),        # dense symmetric M^-1, leading dimension padded to a multiple of 4 (16-byte aligned rows -> ds_read_b128)
                        ("QDD", _pad4(n)),
                        ("F", 0 if self.register_walk else _pad4(6 * n)),                # wave-uniform link forces parked between the two sweeps of the gradient walk
