@@ -162,6 +162,23 @@ def gen_tip_frame_library(self):
             self.gen_add_code_line("#pragma unroll")
             self.gen_add_code_line("for (int r = 0; r < N; r++) { x[r] += mk[%d]*%s<%d>(x[r]); }" % (s_, fn, k))
         self.gen_add_end_function()
+    import os
+    if os.environ.get("GRID_DPP_ASM", "1") == "1":
+        # fp32 device code: one v_fmac_f32_dpp per value and step instead of the v_mov_b32_dpp + v_fma pair the compiler emits for the
+        # builtin (it does not fold the DPP move into the FMA).  The hazard recognizer does not look inside inline asm, so every block
+        # opens with the 2 wait states a DPP read needs after a VALU write of the same register.
+        self.gen_add_code_line("#if defined(__HIP_DEVICE_COMPILE__)")
+        for name, ctrl in (("prefix", "row_shr"), ("suffix", "row_shl")):
+            for N in (6, 10, 12):
+                self.gen_add_code_line("__device__ __forceinline__ void grid_%s_sum(float (&x)[%d], const float (&mk)[GRID_SCAN_STEPS]) {" % (name, N), True)
+                for s_, k in enumerate(steps):
+                    for lo in range(0, N, 6):
+                        cnt = min(6, N - lo)
+                        body = "s_nop 1" + "".join("\\n\\tv_fmac_f32_dpp %%%d, %%%d, %%%d %s:%d row_mask:0xf bank_mask:0xf bound_ctrl:1" % (r, r, cnt, ctrl, k) for r in range(cnt))
+                        outs = ", ".join('"+v"(x[%d])' % (lo + r) for r in range(cnt))
+                        self.gen_add_code_line('asm("%s" : %s : "v"(mk[%d]));' % (body, outs, s_))
+                self.gen_add_end_function()
+        self.gen_add_code_line("#endif")
     self.gen_add_code_line("")
 
 
@@ -248,7 +265,7 @@ def _emit_link_setup(self):
     self.gen_add_code_line("T v[6];")
     self.gen_add_code_line("#pragma unroll")
     self.gen_add_code_line("for (int r = 0; r < 6; r++) { v[r] = S[r]*qd; }")
-    self.gen_add_code_line("grid_prefix_sum<6>(v, mku); // v_j = sum over the ancestors of S_k qd_k")
+    self.gen_add_code_line("grid_prefix_sum(v, mku); // v_j = sum over the ancestors of S_k qd_k")
     self.gen_add_code_line("T Pd[6]; grid_mxm(Pd, v, S); // = S_j-dot")
 
 
@@ -260,7 +277,7 @@ def _emit_bias(self, with_qdd):
         self.gen_add_code_line("for (int r = 0; r < 6; r++) { a[r] = Pd[r]*qd + S[r]*qdd; }")
     else:
         self.gen_add_code_line("for (int r = 0; r < 6; r++) { a[r] = Pd[r]*qd; }")
-    self.gen_add_code_line("grid_prefix_sum<6>(a, mku);")
+    self.gen_add_code_line("grid_prefix_sum(a, mku);")
     self.gen_add_code_line("a[3] += gvec[0]; a[4] += gvec[1]; a[5] += gvec[2];")
     self.gen_add_code_line("T IC[10], BC[12], fC[6];")
     self.gen_add_code_line("{", True)
@@ -282,7 +299,7 @@ def _emit_bias(self, with_qdd):
     self.gen_add_end_control_flow()
     self.gen_add_code_line("#pragma unroll")
     self.gen_add_code_line("for (int r = 0; r < 10; r++) { IC[r] = I[r]; }")
-    self.gen_add_code_line("grid_suffix_sum<10>(IC, mkd); grid_suffix_sum<12>(BC, mkd); grid_suffix_sum<6>(fC, mkd); // composites over the links j..n-1")
+    self.gen_add_code_line("grid_suffix_sum(IC, mkd); grid_suffix_sum(BC, mkd); grid_suffix_sum(fC, mkd); // composites over the links j..n-1")
 
 
 def _emit_assembly(self, s_G="s_G", dst="s_df_du", minv="s_Minv"):
@@ -474,8 +491,8 @@ def gen_forward_dynamics_gradient_inner_tip(self, use_thread_group=False, use_qd
     self.gen_add_code_line("T da[6], Ida[6];")
     self.gen_add_code_line("#pragma unroll")
     self.gen_add_code_line("for (int r = 0; r < 6; r++) { da[r] = S[r]*qdd; }")
-    self.gen_add_code_line("grid_prefix_sum<6>(da, mku);")
-    self.gen_add_code_line("grid_rbi_mul(Ida, I, da); grid_suffix_sum<6>(Ida, mkd);")
+    self.gen_add_code_line("grid_prefix_sum(da, mku);")
+    self.gen_add_code_line("grid_rbi_mul(Ida, I, da); grid_suffix_sum(Ida, mkd);")
     self.gen_add_code_line("#pragma unroll")
     self.gen_add_code_line("for (int r = 0; r < 6; r++) { a[r] += da[r]; fC[r] += Ida[r]; }")
     self.gen_add_end_control_flow()
