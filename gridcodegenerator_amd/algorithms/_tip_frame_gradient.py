@@ -182,18 +182,26 @@ def gen_tip_frame_library(self):
     self.gen_add_code_line("")
 
 
-def _chain_step(self, i):
-    """Frame-chain step of joint i: keep (R_i, p_i) on lane i, then move the running frame to the parent of i (or, for the root,
-    read off the world's gravity direction).  Emitted inside the M^-1 backward sweep (same joint order)."""
+def _chain_step(self, i, s_F=None):
+    """Frame-chain step of joint i: hand (R_i, p_i) to lane i, then move the running frame to the parent of i (or, for the root,
+    read off the world's gravity direction).  The hand-off is a register select on every lane (s_F None) or one LDS record per joint
+    written by lane 0 and read back by its owner after the chain (s_F = name of the record area, 16 values per joint)."""
     m = self.model
     E_nz = m.X_pattern[i][0]
     r = self.gen_tip_frame_joint_offset(i)
     C = lambda x: "static_cast<T>(" + repr(float(x)) + ")"
     self.gen_add_code_line("{ // tip-frame chain, joint %d: lane %d keeps (R, p) of its own frame; then frame %d -> frame of its parent" % (i, i, i), True)
-    self.gen_add_code_line("#pragma unroll")
-    self.gen_add_code_line("for (int r = 0; r < 9; r++) { myR[r] = (lane == %d) ? Rc[r] : myR[r]; }" % i)
-    self.gen_add_code_line("#pragma unroll")
-    self.gen_add_code_line("for (int r = 0; r < 3; r++) { myp[r] = (lane == %d) ? pc[r] : myp[r]; }" % i)
+    if s_F is None:
+        self.gen_add_code_line("#pragma unroll")
+        self.gen_add_code_line("for (int r = 0; r < 9; r++) { myR[r] = (lane == %d) ? Rc[r] : myR[r]; }" % i)
+        self.gen_add_code_line("#pragma unroll")
+        self.gen_add_code_line("for (int r = 0; r < 3; r++) { myp[r] = (lane == %d) ? pc[r] : myp[r]; }" % i)
+    elif i < m.n - 1:  # (the tip's own frame is the identity: lane n-1 keeps its initial values)
+        self.gen_add_code_line("if (lane == 0) {", True)
+        self.gen_add_code_line("#pragma unroll")
+        self.gen_add_code_line("for (int r = 0; r < 9; r++) { %s[%d + r] = Rc[r]; }" % (s_F, 16 * i))
+        self.gen_add_code_line("%s[%d] = pc[0]; %s[%d] = pc[1]; %s[%d] = pc[2];" % (s_F, 16 * i + 9, s_F, 16 * i + 10, s_F, 16 * i + 11))
+        self.gen_add_end_control_flow()
     self.gen_add_code_line("const T *Ei = &s_X[GRID_X_STRIDE*%d]; // E_%d(q): parent -> child coordinates (row-major)" % (i, i))
     self.gen_add_code_line("T Rn[9];")
     for rr in range(3):
@@ -414,8 +422,18 @@ def gen_forward_dynamics_gradient_inner_tip(self, use_thread_group=False, use_qd
     self.gen_add_code_line("void %s(%s) {" % (name, sig), True)
     _emit_link_constants_load(self)
     _emit_chain_decls(self)
+    import os
+    chain_lds = (not use_qdd_Minv_input) and os.environ.get("GRID_TIP_CHAIN", "select") == "lds"
     for i in range(n - 1, -1, -1):
-        _chain_step(self, i)
+        _chain_step(self, i, "s_G" if chain_lds else None)
+    if chain_lds:
+        self.gen_add_sync(use_thread_group)
+        self.gen_add_code_line("if (lane < %d) { // this lane's own frame (lanes without a joint keep the identity; their link constants are zero)" % (n - 1), True)
+        self.gen_add_code_line("#pragma unroll")
+        self.gen_add_code_line("for (int r = 0; r < 9; r++) { myR[r] = s_G[16*lane + r]; }")
+        self.gen_add_code_line("myp[0] = s_G[16*lane + 9]; myp[1] = s_G[16*lane + 10]; myp[2] = s_G[16*lane + 11];")
+        self.gen_add_end_control_flow()
+        self.gen_add_sync(use_thread_group)  # (orders the record writes below behind these reads for lane-per-thread execution models; free on the GPU)
     if use_qdd_Minv_input:
         self.gen_add_sync(use_thread_group)  # every lane is done with s_X before the hand-off records overwrite it
         _emit_link_setup(self)
@@ -424,7 +442,6 @@ def gen_forward_dynamics_gradient_inner_tip(self, use_thread_group=False, use_qd
         _emit_assembly(self, s_G="s_X")
         self.gen_add_end_function()
         return
-    import os
     stop = int(os.environ.get("GRID_DEBUG_STOP", "0"))  # timing ablation only (results are wrong when set): 5 = chain, 6 = + link setup/bias/record, 7 = + M, factorisation, qdd
     ld = self.minv_ld
     if stop == 5:

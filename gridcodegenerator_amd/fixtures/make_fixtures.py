@@ -9,6 +9,8 @@ No URDF files ship with the reference and URDFParser is not in the build contain
   * hyq     - 12-DoF quadruped-like tree (4 legs x [HAA about x, HFE about y, KFE about y]), synthetic
   * atlas   - 30-DoF humanoid-like tree (back 3, neck 1, arms 2x7, legs 2x6), mixed axes, synthetic
   * mixed5  - 5-DoF branched robot with prismatic joints (edge cases for joint models)
+  * arm6    - 6-DoF serial chain, revolute joints about mixed axes, oblique joint frames, full inertia tensors (synthetic)
+  * chain12 - 12-DoF serial chain, revolute joints about mixed axes (lane group of 16; synthetic)
 Run once; the JSON files are committed.
 """
 import json
@@ -114,8 +116,42 @@ def mixed5():
     ])
 
 
+def arm6():
+    axes = "zyyxyx"
+    xyz = [(0, 0, 0.089), (0, 0.136, 0), (0.425, 0, -0.12), (0.392, 0, 0.093), (0, 0.095, 0), (0.03, 0, 0.082)]
+    rpy = [(0, 0, 0.3), (0, PI / 2, 0), (0.1, 0, 0), (0, -0.25, 0.4), (PI / 2, 0, 0), (0, 0.2, -0.1)]
+    masses = [3.7, 8.393, 2.275, 1.219, 1.219, 0.1879]
+    coms = [(0, -0.01, 0.02), (0.2125, 0.01, 0.1360), (0.15, -0.004, 0.0165), (0.002, 0.003, 0.01), (0, 0.01, -0.004), (0.001, -0.002, 0.02)]
+    diags = [(0.0102, 0.0103, 0.0067), (0.2269, 0.2270, 0.0151), (0.0494, 0.0495, 0.0041), (0.0021, 0.0022, 0.0021), (0.0021, 0.0021, 0.0022), (0.00013, 0.00014, 0.00019)]
+    offs = [(0.0003, -0.0002, 0.0001), (0.004, -0.01, 0.002), (-0.0005, 0.002, 0.0003), (0.0001, 0.0, -0.0001), (0.0, 0.0001, 0.0001), (0.00001, -0.00002, 0.00001)]
+    damp = [0.2, 0.0, 0.1, 0.0, 0.05, 0.0]
+    joints = []
+    for i in range(6):
+        joints.append(dict(name="arm6_joint_%d" % (i + 1), type="revolute", axis=axes[i], parent_link="base" if i == 0 else "arm6_link_%d" % i,
+                           xyz=list(xyz[i]), rpy=list(rpy[i]), damping=damp[i], limits=[-3.1, 3.1],
+                           link=link("arm6_link_%d" % (i + 1), masses[i], coms[i], diags[i], offs[i])))
+    return dict(name="arm6", base_link="base", joints=joints)
+
+
+def chain12():
+    rng = np.random.default_rng(20261004)
+    joints = []
+    for i in range(12):
+        scale = 0.25 * (0.9 ** i)
+        mass = round(6.0 * (0.8 ** i), 4)
+        com = np.round(rng.uniform(-0.4, 0.4, 3) * scale, 4)
+        d = np.round(mass * scale ** 2 * rng.uniform(0.08, 0.3, 3), 6)
+        off = np.round(0.1 * float(d.min()) * rng.uniform(-1, 1, 3), 7)
+        xyz = np.round(rng.uniform(-1, 1, 3) * scale, 4)
+        rpy = [0.0, 0.0, 0.0] if i % 3 == 0 else np.round(rng.uniform(-0.6, 0.6, 3), 3).tolist()
+        joints.append(dict(name="chain12_joint_%d" % (i + 1), type="revolute", axis="zxy"[i % 3], parent_link="base" if i == 0 else "chain12_link_%d" % i,
+                           xyz=xyz.tolist(), rpy=rpy, damping=[0.0, 0.1][i % 2], limits=[-3.1, 3.1],
+                           link=link("chain12_link_%d" % (i + 1), mass, com.tolist(), d.tolist(), off.tolist())))
+    return dict(name="chain12", base_link="base", joints=joints)
+
+
 if __name__ == "__main__":
-    for fn in (iiwa14, hyq, atlas, mixed5):
+    for fn in (iiwa14, hyq, atlas, mixed5, arm6, chain12):
         d = fn()
         with open(os.path.join(HERE, d["name"] + ".json"), "w") as f:
             json.dump(d, f, indent=1)

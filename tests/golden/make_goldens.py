@@ -4,7 +4,7 @@
 running it on our robot fixtures through the duck-typed RobotModel getters.
 
 Runs only in the build container (the reference does not exist on the GPU box); the .npz outputs are
-data (inputs + expected outputs) and are committed.  Usage:  python tests/golden/make_goldens.py
+data (inputs + expected outputs) and are committed.  Usage:  python tests/golden/make_goldens.py [golden name ...]
 """
 import contextlib
 import copy
@@ -30,6 +30,8 @@ CASES = [  # (golden name, fixture, number of states, zero the damping?)
     ("hyq", "hyq", 16, False),
     ("atlas", "atlas", 8, False),
     ("mixed5", "mixed5", 8, False),
+    ("arm6", "arm6", 8, False),
+    ("chain12", "chain12", 8, False),
 ]
 
 
@@ -43,7 +45,10 @@ def sample_inputs(n, count, seed):
 
 
 def main():
+    only = set(sys.argv[1:])
     for gname, fixture, count, nodamp in CASES:
+        if only and gname not in only:
+            continue
         robot = RobotModel.from_fixture(fixture)
         if nodamp:
             desc = copy.deepcopy(robot.desc)

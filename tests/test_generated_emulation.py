@@ -29,7 +29,7 @@ def libs():
     return get
 
 
-@pytest.mark.parametrize("name", ["iiwa14", "hyq", "atlas", "mixed5"])
+@pytest.mark.parametrize("name", ["iiwa14", "hyq", "atlas", "mixed5", "arm6", "chain12"])
 def test_emulated_fd_grad_matches_goldens(name, libs, golden):
     g = golden(name)
     lib = libs(name)
@@ -62,7 +62,8 @@ def test_emulated_one_column_per_lane_variant(name, golden):
 
 
 @pytest.mark.parametrize("name,env", [("iiwa14", {"GRID_GRADIENT_WALK": "lds"}), ("hyq", {"GRID_GRADIENT_WALK": "lds"}), ("atlas", {"GRID_GRADIENT_WALK": "lds"}),
-                                      ("iiwa14", {"GRID_REUSE_RNEA": "1"}), ("iiwa14", {"GRID_FUSE_FD": "0"})])
+                                      ("iiwa14", {"GRID_REUSE_RNEA": "1"}), ("iiwa14", {"GRID_FUSE_FD": "0"}),
+                                      ("iiwa14", {"GRID_GRADIENT_WALK": "registers"}), ("iiwa14", {"GRID_TIP_CHAIN": "lds"}), ("arm6", {"GRID_GRADIENT_WALK": "registers"})])
 def test_emulated_generation_variants(name, env, golden):
     """The non-default generated forms stay correct: LDS-assisted forward accumulation of the derivative walk (what deep trees get),
     RNEA re-use, unfused forward dynamics."""
@@ -108,7 +109,7 @@ def test_emulated_empty_batch_is_a_noop(libs):
     assert out.shape == (0, 98)
 
 
-@pytest.mark.parametrize("name", ["iiwa14", "hyq", "mixed5"])
+@pytest.mark.parametrize("name", ["iiwa14", "hyq", "mixed5", "arm6", "chain12"])
 def test_emulated_component_kernels(name, libs, golden):
     g = golden(name)
     lib = libs(name)

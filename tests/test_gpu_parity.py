@@ -11,7 +11,7 @@ from gridcodegenerator_amd.runtime import build_library, GridLibrary
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-4
-ROBOTS = ["iiwa14", "hyq", "atlas", "mixed5"]
+ROBOTS = ["iiwa14", "hyq", "atlas", "mixed5", "arm6", "chain12"]
 
 
 @pytest.fixture(scope="module")
@@ -67,7 +67,7 @@ def test_fd_grad_matches_reference_goldens(name, torch_cuda, libs, golden):
     assert per_solve_err(out, ref) <= TOL
 
 
-@pytest.mark.parametrize("name,N", [("iiwa14", 1), ("iiwa14", 37), ("iiwa14", 1024), ("hyq", 4096), ("atlas", 257), ("mixed5", 100)])
+@pytest.mark.parametrize("name,N", [("iiwa14", 1), ("iiwa14", 37), ("iiwa14", 1024), ("hyq", 4096), ("atlas", 257), ("mixed5", 100), ("arm6", 333), ("chain12", 129)])
 def test_fd_grad_matches_oracle_on_seeded_inputs(name, N, torch_cuda, libs):
     from oracle.rbd_oracle import Oracle
 
@@ -139,7 +139,7 @@ def test_full_batch_16384_properties(torch_cuda, libs):
     assert (np.abs(got - fd) / scale).max() < 5e-2  # fp32 finite differences are crude; this catches layout/sign errors
 
 
-@pytest.mark.parametrize("name", ["iiwa14", "hyq", "mixed5"])
+@pytest.mark.parametrize("name", ["iiwa14", "hyq", "mixed5", "arm6", "chain12"])
 def test_component_kernels_match_goldens(name, torch_cuda, libs, golden):
     """inverse_dynamics, direct_minv, forward_dynamics, inverse_dynamics_gradient."""
     torch = torch_cuda

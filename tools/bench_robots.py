@@ -4,7 +4,7 @@ sys.path.insert(0, ".")
 import numpy as np, torch
 from gridcodegenerator_amd import RobotModel
 from gridcodegenerator_amd.runtime import load
-for name, N in (("iiwa14", 1024), ("iiwa14", 16384), ("iiwa14", 131072), ("hyq", 4096), ("hyq", 65536), ("atlas", 2048), ("atlas", 16384)):
+for name, N in (("iiwa14", 1024), ("iiwa14", 16384), ("iiwa14", 131072), ("hyq", 4096), ("hyq", 65536), ("atlas", 2048), ("atlas", 16384), ("arm6", 16384), ("chain12", 16384)):
     robot = RobotModel.from_fixture(name); n = robot.n
     lib = load(name, max_timesteps=N)
     rng = np.random.default_rng(0)
