@@ -41,7 +41,8 @@ class GRiDCodeGenerator:
         gen_forward_dynamics_gradient_inner_python, gen_forward_dynamics_gradient_device, gen_forward_dynamics_gradient_kernel, \
         gen_forward_dynamics_gradient_host, gen_forward_dynamics_gradient, gen_forward_dynamics_gradient_device_function_call, \
         gen_tip_frame_link_constants, gen_tip_frame_joint_offset, gen_tip_frame_library, gen_forward_dynamics_gradient_inner_tip, \
-        gen_forward_dynamics_gradient_inner_tip_function_call, gen_tip_frame_gradient
+        gen_forward_dynamics_gradient_inner_tip_function_call, gen_tip_frame_gradient, \
+        gen_inverse_dynamics_inner_tip, gen_inverse_dynamics_gradient_inner_tip, gen_forward_dynamics_inner_tip, gen_direct_minv_inner_tip, gen_tip_frame_components
 
     # NumPy debug helpers with the reference's names and signatures (reference GRiDCodeGenerator.py:50-51, README "Additional Features")
     from ._test import test_rnea, test_minv, test_rnea_grad, test_fd_grad
@@ -289,6 +290,8 @@ class GRiDCodeGenerator:
         self.gen_init_robotModel()
         self.gen_init_gridData()
         self.gen_load_update_XImats_helpers(use_thread_group)
+        if self.tip_frame:
+            self.gen_tip_frame_components(use_thread_group)
         # the dynamics algorithms on (and next to) the forward-dynamics-gradient path
         self.gen_inverse_dynamics(use_thread_group)
         self.gen_direct_minv(use_thread_group)

@@ -190,6 +190,12 @@ def gen_direct_minv_device(self, use_thread_group=False):
     self.gen_add_code_line("void direct_minv_device(T *s_Minv, const T *s_q, T *s_work, const robotModel<T> *d_robotModel, const int lane) {", True)
     self.gen_add_code_line("T *s_X = &s_work[GRID_OFF_X]; T *s_U = &s_work[GRID_OFF_U]; T *s_T = &s_work[GRID_OFF_T];")
     self.gen_load_update_XImats_helpers_function_call(use_thread_group)
+    if self.tip_frame:  # serial revolute chains: M from the tip-frame composites, factored in registers, one unit-vector solve per lane
+        self.gen_add_code_line("(void)s_T;")
+        self.gen_add_code_line("direct_minv_inner_tip<T>(s_Minv, s_X, s_U, d_robotModel, lane);")
+        self.gen_add_sync(use_thread_group)
+        self.gen_add_end_function()
+        return
     self.gen_direct_minv_inner_function_call(use_thread_group)
     self.gen_add_end_function()
 

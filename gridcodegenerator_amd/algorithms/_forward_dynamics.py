@@ -120,6 +120,12 @@ def gen_forward_dynamics_device(self, use_thread_group=False):
     self.gen_add_code_line("void forward_dynamics_device(T *s_qdd, const T *s_q, const T *s_qd, const T *s_u, T *s_work, const robotModel<T> *d_robotModel, const T gravity, const int lane) {", True)
     self.gen_add_code_line("T *s_X = &s_work[GRID_OFF_X]; T *s_U = &s_work[GRID_OFF_U]; T *s_T = &s_work[GRID_OFF_T]; T *s_Minv = &s_work[GRID_OFF_MINV];")
     self.gen_load_update_XImats_helpers_function_call(use_thread_group)
+    if self.tip_frame:  # serial revolute chains: M from the tip-frame composites, factored in registers
+        self.gen_add_code_line("(void)s_T;")
+        self.gen_add_code_line("forward_dynamics_inner_tip<T>(s_qdd, s_qd, s_u, s_X, s_U, s_Minv, gravity, d_robotModel, lane);")
+        self.gen_add_sync(use_thread_group)
+        self.gen_add_end_function()
+        return
     self.gen_forward_dynamics_inner_function_call(use_thread_group)
     self.gen_add_end_function()
 

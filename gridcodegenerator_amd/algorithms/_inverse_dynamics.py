@@ -105,6 +105,11 @@ def gen_inverse_dynamics_device(self, use_thread_group=False, use_qdd_input=Fals
                            "T *s_work, const robotModel<T> *d_robotModel, const T gravity, const int lane) {", True)
     self.gen_add_code_line("T *s_X = &s_work[GRID_OFF_X];")
     self.gen_load_update_XImats_helpers_function_call(use_thread_group)
+    if self.tip_frame:  # serial revolute chains: RNEA in the tip link's frame, lane j produces c[j]
+        self.gen_add_code_line("inverse_dynamics_inner_tip<T>(s_c, s_qd, %s, s_X, gravity, d_robotModel, lane);" % ("s_qdd" if use_qdd_input else "static_cast<const T *>(nullptr)"))
+        self.gen_add_sync(use_thread_group)
+        self.gen_add_end_function()
+        return
     self.gen_add_code_line("T c[%d];" % n)
     self.gen_inverse_dynamics_inner_function_call(use_thread_group, True, use_qdd_input)
     self.gen_add_code_line("if (lane == 0) {", True)

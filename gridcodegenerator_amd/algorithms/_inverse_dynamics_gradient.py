@@ -349,6 +349,12 @@ def gen_inverse_dynamics_gradient_device(self, use_thread_group=False, use_qdd_i
         self.gen_add_code_line("T *s_qdd = &s_work[GRID_OFF_QDD];")
         self.gen_add_code_line("if (lane < %d) { s_qdd[lane] = static_cast<T>(0); }" % n)
     self.gen_load_update_XImats_helpers_function_call(use_thread_group)
+    if self.tip_frame:  # serial revolute chains: assembled in the tip link's frame
+        self.gen_add_code_line("(void)s_F; (void)s_J;")
+        self.gen_add_code_line("inverse_dynamics_gradient_inner_tip<T>(s_dc_du, s_qd, s_qdd, s_X, gravity, d_robotModel, lane);")
+        self.gen_add_sync(use_thread_group)
+        self.gen_add_end_function()
+        return
     self.gen_add_code_line(self.gen_gradient_outputs_decl())
     self.gen_inverse_dynamics_gradient_inner_function_call(use_thread_group)
     self.gen_dc_du_to_lds("s_dc_du")

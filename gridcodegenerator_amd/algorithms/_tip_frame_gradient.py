@@ -182,7 +182,7 @@ def gen_tip_frame_library(self):
     self.gen_add_code_line("")
 
 
-def _chain_step(self, i, s_F=None):
+def _chain_step(self, i, s_F=None, with_gravity=True):
     """Frame-chain step of joint i: hand (R_i, p_i) to lane i, then move the running frame to the parent of i (or, for the root,
     read off the world's gravity direction).  The hand-off is a register select on every lane (s_F None) or one LDS record per joint
     written by lane 0 and read back by its owner after the chain (s_F = name of the record area, 16 values per joint)."""
@@ -215,8 +215,10 @@ def _chain_step(self, i, s_F=None):
                 self.gen_add_code_line("pc[%d] -= %s;" % (rr, " + ".join(terms)))
         self.gen_add_code_line("#pragma unroll")
         self.gen_add_code_line("for (int r = 0; r < 9; r++) { Rc[r] = Rn[r]; }")
-    else:
+    elif with_gravity:
         self.gen_add_code_line("gvec[0] = gravity*Rn[2]; gvec[1] = gravity*Rn[5]; gvec[2] = gravity*Rn[8]; // base acceleration (0,0,g) in F coordinates")
+    else:
+        self.gen_add_code_line("(void)Rn; gvec[0] = gvec[1] = gvec[2] = static_cast<T>(0);")
     self.gen_add_end_control_flow()
 
 
@@ -231,8 +233,8 @@ def _emit_chain_decls(self):
     self.gen_add_code_line("for (int r = 0; r < 3; r++) { myp[r] = pc[r]; }")
 
 
-def _emit_link_setup(self):
-    """Per lane: joint axis S and link inertia in F coordinates; velocity prefix sum; Pd; bias acceleration (qdd = 0)."""
+def _emit_link_setup(self, kinematics=True):
+    """Per lane: joint axis S and link inertia in F coordinates; with kinematics also the velocity prefix sum and Pd = S-dot."""
     m = self.model
     n = m.n
     same_axis = len(set(m.S_index)) == 1
@@ -240,7 +242,8 @@ def _emit_link_setup(self):
     self.gen_add_code_line("// tip frame, lane j <-> joint j: joint axis, link inertia, velocity, bias acceleration / force, Coriolis matrix")
     self.gen_add_code_line("//")
     self.gen_add_code_line("T mku[GRID_SCAN_STEPS], mkd[GRID_SCAN_STEPS]; grid_prefix_masks(mku, lane); grid_suffix_masks(mkd, lane);")
-    self.gen_add_code_line("const T qd = s_qd[lane]; // (lanes without a joint read a neighbouring finite value: their inertia is zero and nothing reads their prefix sums)")
+    if kinematics:
+        self.gen_add_code_line("const T qd = s_qd[lane]; // (lanes without a joint read a neighbouring finite value: their inertia is zero and nothing reads their prefix sums)")
     self.gen_add_code_line("T S[6];")
     if same_axis:
         a = m.S_index[0]
@@ -270,6 +273,8 @@ def _emit_link_setup(self):
             self.gen_add_code_line("I[%d] = %s - md%d*d[%d];" % (k, rot, r_, c_))
     self.gen_add_code_line("I[6] = md0; I[7] = md1; I[8] = md2; I[9] = Lc[9];")
     self.gen_add_end_control_flow()
+    if not kinematics:
+        return
     self.gen_add_code_line("T v[6];")
     self.gen_add_code_line("#pragma unroll")
     self.gen_add_code_line("for (int r = 0; r < 6; r++) { v[r] = S[r]*qd; }")
@@ -540,6 +545,156 @@ def gen_forward_dynamics_gradient_inner_tip_function_call(self, use_thread_group
         self.gen_add_code_line("forward_dynamics_gradient_inner_tip_qdd_minv<T>(%s, s_qd, s_qdd, s_Minv, s_X, d_robotModel, gravity, lane);" % s_df_du_name)
     else:
         self.gen_add_code_line("forward_dynamics_gradient_inner_tip<T>(%s, s_qd, s_u, s_X, s_U, s_Minv, d_robotModel, gravity, lane); // hand-off records in the U|T scratch, M in the M^-1 slot" % s_df_du_name)
+
+
+def _emit_force_only(self, with_qdd):
+    """a and the composite force f^C only (no Coriolis matrix): what RNEA itself needs."""
+    self.gen_add_code_line("T a[6], fC[6];")
+    self.gen_add_code_line("#pragma unroll")
+    if with_qdd:
+        self.gen_add_code_line("for (int r = 0; r < 6; r++) { a[r] = Pd[r]*qd + S[r]*qdd; }")
+    else:
+        self.gen_add_code_line("for (int r = 0; r < 6; r++) { a[r] = Pd[r]*qd; }")
+    self.gen_add_code_line("grid_prefix_sum(a, mku);")
+    self.gen_add_code_line("a[3] += gvec[0]; a[4] += gvec[1]; a[5] += gvec[2];")
+    self.gen_add_code_line("{ T Iv[6]; grid_rbi_mul(Iv, I, v); grid_rbi_mul(fC, I, a); grid_fxv_peq(fC, v, Iv); }")
+    self.gen_add_code_line("grid_suffix_sum(fC, mkd); // force transmitted across joint j: sum over the links j..n-1")
+
+
+def _emit_mass_matrix_factor(self, use_thread_group, rhs_expr=None):
+    """IC -> t1 = I^C S, record [S | t1 | . | rhs], M column by dots, hand-off, wave-uniform factorisation (leaves Uf*, rd*; rhs[] if asked)."""
+    n = self.model.n
+    ld = self.minv_ld
+    self.gen_add_code_line("T t1[6]; grid_rbi_mul(t1, IC, S);")
+    self.gen_add_code_line("if (lane < %d) {" % n, True)
+    self.gen_add_code_line("T *rec = &s_G[16*lane];")
+    self.gen_add_code_line("#pragma unroll")
+    self.gen_add_code_line("for (int r = 0; r < 6; r++) { rec[r] = S[r]; }")
+    if rhs_expr is not None:
+        self.gen_add_code_line("rec[6] = %s;" % rhs_expr)
+    self.gen_add_end_control_flow()
+    self.gen_add_sync(use_thread_group)
+    self.gen_add_code_line("T Mcol[%d]%s;" % (ld, (", rhs[%d]" % n) if rhs_expr is not None else ""))
+    for k in range(n, ld):
+        self.gen_add_code_line("Mcol[%d] = static_cast<T>(0);" % k)
+    self.gen_add_code_line("#pragma unroll")
+    self.gen_add_code_line("for (int k = 0; k < %d; k++) { // M[k][lane] = S_k . (I^C_lane S_lane), rows k <= lane" % n, True)
+    self.gen_add_code_line("T g[8];")
+    self.gen_add_code_line("#pragma unroll")
+    self.gen_add_code_line("for (int r = 0; r < 8; r++) { g[r] = s_G[16*k + r]; }")
+    self.gen_add_code_line("Mcol[k] = g[0]*t1[0] + g[1]*t1[1] + g[2]*t1[2] + g[3]*t1[3] + g[4]*t1[4] + g[5]*t1[5];")
+    if rhs_expr is not None:
+        self.gen_add_code_line("rhs[k] = g[6];")
+    self.gen_add_end_control_flow()
+    self.gen_add_code_line("if (lane < %d) {" % n, True)
+    self.gen_add_code_line("#pragma unroll")
+    self.gen_add_code_line("for (int k = 0; k < %d; k++) { s_M[%d*lane + k] = Mcol[k]; }" % (ld, ld))
+    self.gen_add_end_control_flow()
+    self.gen_add_sync(use_thread_group)
+    for j in range(n):
+        self.gen_add_code_line(" ".join("T A%d_%d = s_M[%d];" % (i, j, ld * j + i) for i in range(j + 1)))
+    _emit_ldl_factor(self)
+
+
+def _tip_inner_header(self, name, doc, notes, params, sig, with_gravity=True):
+    self.gen_add_func_doc(doc, ["serial revolute chains: computed in the frame of the tip link (algorithms/_tip_frame_gradient.py)"] + notes,
+                          params + ["d_robotModel is the pointer to the initialized model specific helpers on the GPU", "lane is the caller's lane index inside the solve's lane group"], None)
+    self.gen_add_code_line("template <typename T>")
+    self.gen_add_code_line("__device__ __forceinline__")
+    self.gen_add_code_line("void %s(%s, const robotModel<T> *d_robotModel, const int lane) {" % (name, sig), True)
+    _emit_link_constants_load(self)
+    _emit_chain_decls(self)
+    for i in range(self.model.n - 1, -1, -1):
+        _chain_step(self, i, None, with_gravity)
+
+
+def gen_inverse_dynamics_inner_tip(self, use_thread_group=False):
+    """c = S . f^C + damping*qd per joint (RNEA, oracle /root/reference/_test.py:5-115), lane j writes s_c[j]."""
+    n = self.model.n
+    _tip_inner_header(self, "inverse_dynamics_inner_tip", "Compute the RNEA (Recursive Newton-Euler Algorithm)", ["lane j writes s_c[j]; the caller must grid_wave_sync() before other lanes read it"],
+                      ["s_c is the output vector of joint torques in LDS", "s_qd is the vector of joint velocities in LDS",
+                       "s_qdd is the vector of joint accelerations in LDS, or nullptr for qdd = 0", "s_X is this solve's compact X(q) storage", "gravity is the gravity constant"],
+                      "T *s_c, const T *s_qd, const T *s_qdd, const T *s_X, const T gravity")
+    _emit_link_setup(self)
+    self.gen_add_code_line("const T qdd = (s_qdd != nullptr) ? s_qdd[lane] : static_cast<T>(0);")
+    _emit_force_only(self, True)
+    self.gen_add_code_line("if (lane < %d) { s_c[lane] = grid_dot6(S, fC) + Lc[10]*qd; }" % n)
+    self.gen_add_end_function()
+
+
+def gen_inverse_dynamics_gradient_inner_tip(self, use_thread_group=False):
+    """dc/du (oracle /root/reference/_test.py:229-494): the assembly of the forward-dynamics-gradient path without the M^-1 product."""
+    _tip_inner_header(self, "inverse_dynamics_gradient_inner_tip", "Computes the gradient of inverse dynamics",
+                      ["lane j writes columns j and n+j of s_dc_du ([col*n + row]); the caller must grid_wave_sync() before other lanes read them"],
+                      ["s_dc_du is the output in LDS, 2*NUM_JOINTS*NUM_JOINTS values", "s_qd is the vector of joint velocities in LDS",
+                       "s_qdd is the vector of joint accelerations in LDS", "s_X is this solve's compact X(q) storage; it is overwritten by the per-joint hand-off records",
+                       "gravity is the gravity constant"],
+                      "T *s_dc_du, const T *s_qd, const T *s_qdd, T *s_X, const T gravity")
+    self.gen_add_sync(use_thread_group)  # every lane is done with s_X before the hand-off records overwrite it
+    _emit_link_setup(self)
+    self.gen_add_code_line("const T qdd = s_qdd[lane];")
+    _emit_bias(self, True)
+    _emit_assembly(self, s_G="s_X", dst="s_dc_du", minv=None)
+    self.gen_add_end_function()
+
+
+def gen_forward_dynamics_inner_tip(self, use_thread_group=False):
+    """qdd = M^-1 (u - c) with M from the tip-frame composites, factored in registers (oracle /root/reference/_test.py:498-501)."""
+    n = self.model.n
+    _tip_inner_header(self, "forward_dynamics_inner_tip", "Computes forward dynamics", ["lane j writes s_qdd[j]; the caller must grid_wave_sync() before other lanes read it"],
+                      ["s_qdd is the output vector of joint accelerations in LDS", "s_qd is the vector of joint velocities in LDS", "s_u is the vector of joint input torques in LDS",
+                       "s_X is this solve's compact X(q) storage", "s_G is LDS scratch for the per-joint hand-off records (16 values per joint)",
+                       "s_M is LDS scratch for the joint-space inertia matrix (leading dimension GRID_MINV_LD)", "gravity is the gravity constant"],
+                      "T *s_qdd, const T *s_qd, const T *s_u, const T *s_X, T *s_G, T *s_M, const T gravity")
+    _emit_link_setup(self)
+    _emit_force_only(self, False)
+    self.gen_add_code_line("T IC[10];")
+    self.gen_add_code_line("#pragma unroll")
+    self.gen_add_code_line("for (int r = 0; r < 10; r++) { IC[r] = I[r]; }")
+    self.gen_add_code_line("grid_suffix_sum(IC, mkd);")
+    _emit_mass_matrix_factor(self, use_thread_group, rhs_expr="s_u[lane] - (grid_dot6(S, fC) + Lc[10]*qd)")
+    _emit_ldl_solve(self, "rhs")
+    sel = "rhs[0]"
+    for k in range(1, n):
+        sel = "((lane == %d) ? rhs[%d] : %s)" % (k, k, sel)
+    self.gen_add_code_line("if (lane < %d) { s_qdd[lane] = %s; }" % (n, sel))
+    self.gen_add_end_function()
+
+
+def gen_direct_minv_inner_tip(self, use_thread_group=False):
+    """M^-1 (dense, symmetric): lane j solves M x = e_j with the register factors (oracle /root/reference/_test.py:117-226 gives the same matrix)."""
+    n = self.model.n
+    ld = self.minv_ld
+    _tip_inner_header(self, "direct_minv_inner_tip", "Compute the inverse of the mass matrix (dense, symmetric) into LDS",
+                      ["lane j writes row j (= column j); the caller must grid_wave_sync() before other lanes' entries are read"],
+                      ["s_Minv is the n x n output in LDS (leading dimension GRID_MINV_LD); it also holds M itself on the way",
+                       "s_X is this solve's compact X(q) storage", "s_G is LDS scratch for the per-joint hand-off records (16 values per joint)"],
+                      "T *s_Minv, const T *s_X, T *s_G", with_gravity=False)
+    self.gen_add_code_line("T *s_M = s_Minv;")
+    _emit_link_setup(self, kinematics=False)
+    self.gen_add_code_line("T IC[10];")
+    self.gen_add_code_line("#pragma unroll")
+    self.gen_add_code_line("for (int r = 0; r < 10; r++) { IC[r] = I[r]; }")
+    self.gen_add_code_line("grid_suffix_sum(IC, mkd);")
+    _emit_mass_matrix_factor(self, use_thread_group)
+    self.gen_add_code_line("T x[%d];" % n)
+    self.gen_add_code_line("#pragma unroll")
+    self.gen_add_code_line("for (int k = 0; k < %d; k++) { x[k] = (k == lane) ? static_cast<T>(1) : static_cast<T>(0); }" % n)
+    _emit_ldl_solve(self, "x")
+    self.gen_add_sync(use_thread_group)  # every lane has read M before the same slot receives M^-1
+    self.gen_add_code_line("if (lane < %d) {" % n, True)
+    self.gen_add_code_line("#pragma unroll")
+    self.gen_add_code_line("for (int k = 0; k < %d; k++) { s_Minv[%d*lane + k] = x[k]; }" % (n, ld))
+    self.gen_add_end_control_flow()
+    self.gen_add_code_line("(void)gvec; (void)mku;")
+    self.gen_add_end_function()
+
+
+def gen_tip_frame_components(self, use_thread_group=False):
+    self.gen_inverse_dynamics_inner_tip(use_thread_group)
+    self.gen_inverse_dynamics_gradient_inner_tip(use_thread_group)
+    self.gen_forward_dynamics_inner_tip(use_thread_group)
+    self.gen_direct_minv_inner_tip(use_thread_group)
 
 
 def gen_tip_frame_gradient(self, use_thread_group=False):
