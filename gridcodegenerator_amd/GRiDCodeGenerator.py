@@ -34,6 +34,7 @@ class GRiDCodeGenerator:
         gen_forward_dynamics_inner_temp_mem_size, gen_forward_dynamics_finish_function_call, gen_forward_dynamics_finish, \
         gen_forward_dynamics_inner_function_call, gen_forward_dynamics_inner, gen_forward_dynamics_device, gen_forward_dynamics_kernel, \
         gen_forward_dynamics_host, gen_forward_dynamics, \
+        gen_aba_inner_temp_mem_size, gen_aba_inner_function_call, gen_aba_inner, gen_aba_device, gen_aba_kernel, gen_aba_host, gen_aba, \
         gen_inverse_dynamics_gradient_inner_temp_mem_size, gen_inverse_dynamics_gradient_kernel_max_temp_mem_size, \
         gen_inverse_dynamics_gradient_inner_function_call, gen_inverse_dynamics_gradient_inner, gen_dc_du_to_lds, gen_gradient_slots, gen_gradient_outputs_decl, \
         gen_inverse_dynamics_gradient_device, gen_inverse_dynamics_gradient_kernel, gen_inverse_dynamics_gradient_host, gen_inverse_dynamics_gradient, \
@@ -152,7 +153,7 @@ class GRiDCodeGenerator:
                                  "// the *_DYNAMIC_SHARED_MEM_COUNT constants below are that amount for SUGGESTED_THREADS"])
         for k in ("IN", "X", "U", "T", "MINV", "QDD", "F", "J"):
             self.gen_add_code_line("const int GRID_OFF_" + k + " = " + str(lds[k]) + ";")
-        for k in ("ID", "MINV", "FD", "ID_DU", "FD_DU"):
+        for k in ("ID", "MINV", "FD", "ABA", "ID_DU", "FD_DU"):
             self.gen_add_code_line("const int " + k + "_DYNAMIC_SHARED_MEM_COUNT = " + str(count) + ";")
         self.gen_add_code_lines(["const int ID_DU_MAX_SHARED_MEM_COUNT = " + str(count) + ";",
                                  "const int FD_DU_MAX_SHARED_MEM_COUNT = " + str(count) + ";",
@@ -296,6 +297,7 @@ class GRiDCodeGenerator:
         self.gen_inverse_dynamics(use_thread_group)
         self.gen_direct_minv(use_thread_group)
         self.gen_forward_dynamics(use_thread_group)
+        self.gen_aba(use_thread_group)
         self.gen_inverse_dynamics_gradient(use_thread_group)
         if self.tip_frame:
             self.gen_tip_frame_gradient(use_thread_group)

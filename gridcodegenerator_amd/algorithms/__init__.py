@@ -1,6 +1,7 @@
 from ._inverse_dynamics import *
 from ._direct_minv import *
 from ._forward_dynamics import *
+from ._aba import *
 from ._inverse_dynamics_gradient import *
 from ._forward_dynamics_gradient import *
 from ._tip_frame_gradient import gen_tip_frame_link_constants, gen_tip_frame_joint_offset, gen_tip_frame_library, \

@@ -185,6 +185,18 @@ int grid_forward_dynamics_device(grid_handle *h, const float *d_q_qd_u, int stri
     return 0;
 }
 
+int grid_aba_device(grid_handle *h, const float *d_q_qd_tau, int stride_q_qd, int num_timesteps, float gravity, float *d_qdd, void *stream) {
+    int rc = check_args(h, num_timesteps);
+    if (rc) return rc;
+    if (num_timesteps == 0) return 0;
+    dim3 grid, block;
+    launch_dims(h, num_timesteps, &grid, &block);
+    hipLaunchKernelGGL((grid::aba_kernel<float>), grid, block, lds_bytes(h), (hipStream_t)stream,
+                       d_qdd, d_q_qd_tau, stride_q_qd, h->d_robotModel, gravity, num_timesteps);
+    GRID_TRY(hipGetLastError());
+    return 0;
+}
+
 int grid_inverse_dynamics_gradient_device(grid_handle *h, const float *d_q_qd, int stride_q_qd, const float *d_qdd, int num_timesteps, float gravity,
                                           float *d_dc_du, void *stream) {
     int rc = check_args(h, num_timesteps);

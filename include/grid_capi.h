@@ -64,6 +64,8 @@ int grid_inverse_dynamics_device(grid_handle *h, const float *d_q_qd, int stride
 int grid_direct_minv_device(grid_handle *h, const float *d_q, int stride_q, int num_timesteps, float *d_Minv, void *stream);
 /* replaces forward_dynamics_kernel<T> (reference algorithms/_forward_dynamics.py:149-199) */
 int grid_forward_dynamics_device(grid_handle *h, const float *d_q_qd_u, int stride_q_qd_u, int num_timesteps, float gravity, float *d_qdd, void *stream);
+/* replaces aba_kernel<T> (reference algorithms/_aba.py:482-537): O(n) articulated-body forward dynamics, same result as grid_forward_dynamics_device */
+int grid_aba_device(grid_handle *h, const float *d_q_qd_tau, int stride_q_qd, int num_timesteps, float gravity, float *d_qdd, void *stream);
 /* replaces inverse_dynamics_gradient_kernel<T> (reference algorithms/_inverse_dynamics_gradient.py:817-888); d_qdd may be NULL */
 int grid_inverse_dynamics_gradient_device(grid_handle *h, const float *d_q_qd, int stride_q_qd, const float *d_qdd, int num_timesteps, float gravity,
                                           float *d_dc_du, void *stream);

@@ -109,7 +109,7 @@ def test_emulated_empty_batch_is_a_noop(libs):
     assert out.shape == (0, 98)
 
 
-@pytest.mark.parametrize("name", ["iiwa14", "hyq", "mixed5", "arm6", "chain12"])
+@pytest.mark.parametrize("name", ["iiwa14", "hyq", "atlas", "mixed5", "arm6", "chain12"])
 def test_emulated_component_kernels(name, libs, golden):
     g = golden(name)
     lib = libs(name)
@@ -129,6 +129,9 @@ def test_emulated_component_kernels(name, libs, golden):
     out_qdd = np.zeros((N, n), np.float32)
     lib.forward_dynamics_device(x, N, out_qdd)
     assert per_solve_err(out_qdd, g["qdd"]) <= TOL
+    aba_qdd = np.zeros((N, n), np.float32)
+    lib.aba_device(x, N, aba_qdd)  # O(n) articulated-body algorithm: same vector as forward dynamics
+    assert per_solve_err(aba_qdd, g["qdd"]) <= TOL
     dc = np.zeros((N, 2 * n * n), np.float32)
     lib.inverse_dynamics_gradient_device(x, qdd, N, dc)
     assert per_solve_err(dc, np.stack([g["dc_du"][k].T.reshape(-1) for k in range(N)])) <= TOL

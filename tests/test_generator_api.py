@@ -38,6 +38,7 @@ def test_emitted_surface(code):
                  "load_update_XImats_helpers", "inverse_dynamics_inner", "inverse_dynamics_device", "inverse_dynamics_kernel",
                  "inverse_dynamics_kernel_single_timing", "direct_minv_inner", "direct_minv_device", "direct_minv_kernel",
                  "forward_dynamics_finish", "forward_dynamics_inner", "forward_dynamics_device", "forward_dynamics_kernel",
+                 "aba_inner", "aba_device", "aba_kernel", "aba_kernel_single_timing", "void aba(", "void aba_single_timing(", "void aba_compute_only(", "ABA_DYNAMIC_SHARED_MEM_COUNT",
                  "inverse_dynamics_gradient_inner", "inverse_dynamics_gradient_device", "inverse_dynamics_gradient_kernel",
                  "forward_dynamics_gradient_device", "forward_dynamics_gradient_kernel", "forward_dynamics_gradient_kernel_single_timing",
                  "void forward_dynamics_gradient(", "void forward_dynamics_gradient_single_timing(", "void forward_dynamics_gradient_compute_only(",

@@ -139,7 +139,7 @@ def test_full_batch_16384_properties(torch_cuda, libs):
     assert (np.abs(got - fd) / scale).max() < 5e-2  # fp32 finite differences are crude; this catches layout/sign errors
 
 
-@pytest.mark.parametrize("name", ["iiwa14", "hyq", "mixed5", "arm6", "chain12"])
+@pytest.mark.parametrize("name", ["iiwa14", "hyq", "atlas", "mixed5", "arm6", "chain12"])
 def test_component_kernels_match_goldens(name, torch_cuda, libs, golden):
     """inverse_dynamics, direct_minv, forward_dynamics, inverse_dynamics_gradient."""
     torch = torch_cuda
@@ -166,6 +166,10 @@ def test_component_kernels_match_goldens(name, torch_cuda, libs, golden):
     lib.forward_dynamics_device(x, N, out_qdd, stream=st)
     torch.cuda.synchronize()
     assert per_solve_err(out_qdd.cpu().numpy(), g["qdd"]) <= TOL
+    aba_qdd = torch.empty((N, n), dtype=torch.float32, device="cuda")
+    lib.aba_device(x, N, aba_qdd, stream=st)  # articulated-body forward dynamics
+    torch.cuda.synchronize()
+    assert per_solve_err(aba_qdd.cpu().numpy(), g["qdd"]) <= TOL
     dc = torch.empty((N, 2 * n * n), dtype=torch.float32, device="cuda")
     lib.inverse_dynamics_gradient_device(x, qdd, N, dc, stream=st)
     torch.cuda.synchronize()

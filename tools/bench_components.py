@@ -21,7 +21,7 @@ def cpu_time(fn, reps=20):
     for _ in range(reps): fn()
     return 1e6 * (time.perf_counter() - t0) / reps
 
-for name, N in (("iiwa14", 1024), ("iiwa14", 16384)):
+for name, N in (("iiwa14", 1024), ("iiwa14", 16384), ("hyq", 4096), ("atlas", 2048)):
     robot = RobotModel.from_fixture(name); n = robot.n
     lib = load(name, max_timesteps=N)
     orc64, orc32 = Oracle(robot), Oracle(robot, dtype=np.float32)
@@ -40,6 +40,7 @@ for name, N in (("iiwa14", 1024), ("iiwa14", 16384)):
         ("inverse_dynamics_gradient (with qdd)", lambda: lib.inverse_dynamics_gradient_device(d_x, d_qdd, N, d_g, stream=st), d_g, lambda o: o.rnea_grad_batch(x, qdd), 4 * (3 * n + 2 * n * n)),
         ("direct_minv", lambda: lib.direct_minv_device(d_x, N, d_M, stream=st), d_M, lambda o: o.minv_batch(x), 4 * (n + n * n)),
         ("forward_dynamics", lambda: lib.forward_dynamics_device(d_x, N, d_c, stream=st), d_c, None, 4 * (3 * n + n)),
+        ("aba", lambda: lib.aba_device(d_x, N, d_c, stream=st), d_c, None, 4 * (3 * n + n)),
         ("forward_dynamics_gradient", lambda: lib.forward_dynamics_gradient_device(d_x, N, d_g, stream=st), d_g, lambda o: o.fd_grad_batch(x)[0], 4 * (3 * n + 2 * n * n)),
     ]
     gpu_us = [gpu_time(c[1]) for c in cases]  # all GPU timings first: OpenMP workers of the CPU leg spin after a parallel region and starve the launch thread
