@@ -20,10 +20,14 @@ base links.  In the world frame the wrist rows are small differences of large mo
 about a nearby origin and the error is that of the link-local recursion (3e-6).  F is the inertial frame that coincides with
 the tip link at this instant, so all identities hold unchanged.
 
-Lane mapping (chain: lane j <-> joint j, parent = lane j-1): the frame chain tip -> base runs wave-uniformly inside the M^-1
-backward sweep (same joint order, shares its X loads), every lane keeps its own (R_j, p_j); prefix sums over the ancestors
-(v, a) and suffix sums over the subtree (I^C, B^C, f^C) are log-step DPP scans inside the lane group; the only LDS hand-offs are
-tau - c (n floats) and one 16-float record per joint [S | t1 | t4] that every lane reads to assemble its two columns.
+Lane mapping (chain: lane j <-> joint j, parent = lane j-1): the frame chain tip -> base is computed wave-uniformly from the rotation
+blocks of X(q) and every lane keeps its own (R_j, p_j); prefix sums over the ancestors (v, a) and suffix sums over the subtree
+(I^C, B^C, f^C) are log-step DPP scans inside the lane group; the only LDS hand-offs are one 16-float record per joint
+[S | t1 | t4 | tau - c] that every lane reads to assemble its two columns, and the n x n joint-space inertia.
+
+The joint-space inertia needs nothing new: M[k][j] = S_k . (I^C_j S_j) = S_k . t1_j for k <= j.  It is never inverted: every lane factors
+it in registers (U D U^T, wave-uniform) and solves for tau - c (-> qdd) and for its own two columns of dc/du.  The stand-alone kernels
+of such robots (inverse dynamics, its gradient, forward dynamics, M^-1) are subsets of the same code (gen_tip_frame_components).
 
 Scope: serial chains of revolute joints (the reference's own iiwa case).  Robots with prismatic joints stay on the column walk: the
 reference's oracle differs from the true derivative for non-root prismatic joints (checked by finite differences of its own RNEA),
