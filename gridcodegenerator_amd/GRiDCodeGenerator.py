@@ -85,9 +85,14 @@ class GRiDCodeGenerator:
         # forward_dynamics_gradient of serial revolute chains is assembled in the tip link's frame (algorithms/_tip_frame_gradient.py);
         # every other robot, and every other kernel, uses the column walk selected above
         m_ = self.model
-        tip_ok = (all(m_.parent[j] == j - 1 for j in range(n)) and all(s_ < 3 for s_ in m_.S_index) and COLS_PER_LANE == 2 and lanes <= 16)
+        # ... and so do forests of equal chains hanging off the fixed base (a quadruped's legs): one tip frame per chain
+        segs = [(r_, len(m_.subtree[r_])) for r_ in m_.roots]
+        chains = all(len(m_.children[j]) <= 1 for j in range(n))
+        equal = chains and len(set(L_ for _, L_ in segs)) == 1 and all([m_.S_index[st + i] for i in range(L_)] == [m_.S_index[i] for i in range(L_)] for st, L_ in segs)
+        tip_ok = bool(chains and equal and all(s_ < 3 for s_ in m_.S_index) and COLS_PER_LANE == 2 and lanes <= 16)
+        self.tip_L, self.tip_nseg = (segs[0][1], len(segs)) if tip_ok else (n, 1)
         if mode == "tipframe" and not tip_ok:
-            raise NotImplementedError("GRID_GRADIENT_WALK=tipframe needs a serial chain of revolute joints with at most 16 joints")
+            raise NotImplementedError("GRID_GRADIENT_WALK=tipframe needs a serial chain of revolute joints (or a forest of equal such chains) with at most 16 joints")
         self.tip_frame = tip_ok and mode in ("auto", "tipframe") and not DEBUG_MODE  # (DEBUG_MODE prints M^-1, which this path never forms)
         self.reuse_rnea = self.register_walk and n <= 9 and _os.environ.get("GRID_FUSE_FD", "1") == "1" and _os.environ.get("GRID_REUSE_RNEA", "0") == "1"  # measured: 16.6 us vs 15.0 us per launch with re-use (extra LDS traffic on the critical path), so off by default
         # tuning knob: minimum waves per SIMD the register allocator must leave room for (second __launch_bounds__ argument); 0 = compiler's choice

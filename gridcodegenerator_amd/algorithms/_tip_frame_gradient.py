@@ -29,7 +29,11 @@ The joint-space inertia needs nothing new: M[k][j] = S_k . (I^C_j S_j) = S_k . t
 it in registers (U D U^T, wave-uniform) and solves for tau - c (-> qdd) and for its own two columns of dc/du.  The stand-alone kernels
 of such robots (inverse dynamics, its gradient, forward dynamics, M^-1) are subsets of the same code (gen_tip_frame_components).
 
-Scope: serial chains of revolute joints (the reference's own iiwa case).  Robots with prismatic joints stay on the column walk: the
+Forests: a fixed-base robot whose limbs are separate chains hanging off the base (a quadruped's legs) is several independent solves of
+this kind side by side in one lane group - every limb has its own tip frame, its own scans (segments of the lane group), its own
+L x L inertia block; limbs must have the same length and joint-axis sequence so that one instruction stream serves them all.
+
+Scope: serial chains of revolute joints (the reference's own iiwa case) and forests of equal such chains.  Robots with prismatic joints stay on the column walk: the
 reference's oracle differs from the true derivative for non-root prismatic joints (checked by finite differences of its own RNEA),
 and parity with the reference is the contract.
 """
@@ -52,6 +56,10 @@ def gen_tip_frame_link_constants(self):
         c = h / mass
         Ic = I[:3, :3] - mass * (float(c @ c) * np.eye(3) - np.outer(c, c))
         rows += [Ic[0, 0], Ic[0, 1], Ic[0, 2], Ic[1, 1], Ic[1, 2], Ic[2, 2], c[0], c[1], c[2], mass, float(m.damping[j]), float(m.S_index[j])]
+    if self.tip_nseg > 1:  # forests: the chain steps read the joint offsets from a table (they differ between limbs), 4 values per joint
+        for j in range(m.n):
+            r = self.gen_tip_frame_joint_offset(j)
+            rows += [r[0], r[1], r[2], 0.0]
     return rows
 
 
@@ -146,22 +154,26 @@ def gen_tip_frame_library(self):
     """Generic device helpers of the tip-frame path plus the lane-group scans (their step count depends on GRID_LANES_PER_SOLVE)."""
     for line in _TIP_LIBRARY.strip("\n").split("\n"):
         self.gen_add_code_line(line)
-    G = self.lanes_per_solve
-    steps = [k for k in (1, 2, 4, 8) if k < G]
-    ns = len(steps)
+    L = self.tip_L
+    steps = [k for k in (1, 2, 4, 8) if k < L]
+    ns = max(1, len(steps))
     self.gen_add_code_line("")
-    self.gen_add_code_line("// inclusive sums over the lanes of one lane group (lane j <-> joint j of a serial chain): prefix = over joint j and its ancestors,")
-    self.gen_add_code_line("// suffix = over joint j and its descendants.  Log-step DPP scans; mk[s] is 1 where the partner lane of step s is in the same group.")
+    self.gen_add_code_line("// inclusive sums over the lanes of one chain (lane j <-> joint j; pos = position of the joint in its chain of %d): prefix = over joint j" % L)
+    self.gen_add_code_line("// and its ancestors, suffix = over joint j and its descendants.  Log-step DPP scans; mk[s] is 1 where the partner lane of step s is in the same chain.")
     self.gen_add_code_line("#define GRID_SCAN_STEPS %d" % ns)
-    for name, fn, cmp_ in (("prefix", "grid_lane_below", "(lane & %d) >= %d"), ("suffix", "grid_lane_above", "(lane & %d) + %d < %d")):
+    for name, fn, cmp_ in (("prefix", "grid_lane_below", "pos >= %d"), ("suffix", "grid_lane_above", "pos + %d < %d")):
         self.gen_add_code_line("template <typename T>")
-        self.gen_add_code_line("__device__ __forceinline__ void grid_%s_masks(T (&mk)[GRID_SCAN_STEPS], const int lane) {" % name, True)
+        self.gen_add_code_line("__device__ __forceinline__ void grid_%s_masks(T (&mk)[GRID_SCAN_STEPS], const int pos) {" % name, True)
+        if not steps:
+            self.gen_add_code_line("mk[0] = static_cast<T>(0); (void)pos;")
         for s_, k in enumerate(steps):
-            cond = (cmp_ % (G - 1, k)) if name == "prefix" else (cmp_ % (G - 1, k, G))
+            cond = (cmp_ % k) if name == "prefix" else (cmp_ % (k, L))
             self.gen_add_code_line("mk[%d] = (%s) ? static_cast<T>(1) : static_cast<T>(0);" % (s_, cond))
         self.gen_add_end_function()
         self.gen_add_code_line("template <int N, typename T>")
         self.gen_add_code_line("__device__ __forceinline__ void grid_%s_sum(T (&x)[N], const T (&mk)[GRID_SCAN_STEPS]) {" % name, True)
+        if not steps:
+            self.gen_add_code_line("(void)x; (void)mk;")
         for s_, k in enumerate(steps):
             self.gen_add_code_line("#pragma unroll")
             self.gen_add_code_line("for (int r = 0; r < N; r++) { x[r] += mk[%d]*%s<%d>(x[r]); }" % (s_, fn, k))
@@ -175,6 +187,8 @@ def gen_tip_frame_library(self):
         for name, ctrl in (("prefix", "row_shr"), ("suffix", "row_shl")):
             for N in (6, 10, 12):
                 self.gen_add_code_line("__device__ __forceinline__ void grid_%s_sum(float (&x)[%d], const float (&mk)[GRID_SCAN_STEPS]) {" % (name, N), True)
+                if not steps:
+                    self.gen_add_code_line("(void)x; (void)mk;")
                 for s_, k in enumerate(steps):
                     for lo in range(0, N, 6):
                         cnt = min(6, N - lo)
@@ -187,36 +201,45 @@ def gen_tip_frame_library(self):
 
 
 def _chain_step(self, i, s_F=None, with_gravity=True):
-    """Frame-chain step of joint i: hand (R_i, p_i) to lane i, then move the running frame to the parent of i (or, for the root,
-    read off the world's gravity direction).  The hand-off is a register select on every lane (s_F None) or one LDS record per joint
-    written by lane 0 and read back by its owner after the chain (s_F = name of the record area, 16 values per joint)."""
+    """Frame-chain step of the joint at position i of every chain: hand (R, p) to the lane that owns that joint, then move the running
+    frame to the parent (or, for the root, read off the world's gravity direction).  The hand-off is a register select on every lane
+    (s_F None) or one LDS record per joint written by lane 0 and read back by its owner after the chain (single chains only)."""
     m = self.model
-    E_nz = m.X_pattern[i][0]
-    r = self.gen_tip_frame_joint_offset(i)
+    L, nseg = self.tip_L, self.tip_nseg
+    E_nz = m.X_pattern[i][0].copy()
+    for sgi in range(1, nseg):
+        E_nz |= m.X_pattern[sgi * L + i][0]
     C = lambda x: "static_cast<T>(" + repr(float(x)) + ")"
-    self.gen_add_code_line("{ // tip-frame chain, joint %d: lane %d keeps (R, p) of its own frame; then frame %d -> frame of its parent" % (i, i, i), True)
+    J = str(i) if nseg == 1 else "(base + %d)" % i
+    self.gen_add_code_line("{ // tip-frame chain, position %d: the lane of that joint keeps (R, p) of its frame; then on to the frame of its parent" % i, True)
     if s_F is None:
         self.gen_add_code_line("#pragma unroll")
-        self.gen_add_code_line("for (int r = 0; r < 9; r++) { myR[r] = (lane == %d) ? Rc[r] : myR[r]; }" % i)
+        self.gen_add_code_line("for (int r = 0; r < 9; r++) { myR[r] = (pos == %d) ? Rc[r] : myR[r]; }" % i)
         self.gen_add_code_line("#pragma unroll")
-        self.gen_add_code_line("for (int r = 0; r < 3; r++) { myp[r] = (lane == %d) ? pc[r] : myp[r]; }" % i)
-    elif i < m.n - 1:  # (the tip's own frame is the identity: lane n-1 keeps its initial values)
+        self.gen_add_code_line("for (int r = 0; r < 3; r++) { myp[r] = (pos == %d) ? pc[r] : myp[r]; }" % i)
+    elif i < L - 1:  # (the tip's own frame is the identity: its lane keeps the initial values)
         self.gen_add_code_line("if (lane == 0) {", True)
         self.gen_add_code_line("#pragma unroll")
         self.gen_add_code_line("for (int r = 0; r < 9; r++) { %s[%d + r] = Rc[r]; }" % (s_F, 16 * i))
         self.gen_add_code_line("%s[%d] = pc[0]; %s[%d] = pc[1]; %s[%d] = pc[2];" % (s_F, 16 * i + 9, s_F, 16 * i + 10, s_F, 16 * i + 11))
         self.gen_add_end_control_flow()
-    self.gen_add_code_line("const T *Ei = &s_X[GRID_X_STRIDE*%d]; // E_%d(q): parent -> child coordinates (row-major)" % (i, i))
+    self.gen_add_code_line("const T *Ei = &s_X[GRID_X_STRIDE*%s]; // E(q) of that joint: parent -> child coordinates (row-major)" % J)
     self.gen_add_code_line("T Rn[9];")
     for rr in range(3):
         for cc in range(3):
             terms = ["Rc[%d]*Ei[%d]" % (3 * rr + k, 3 * k + cc) for k in range(3) if E_nz[k, cc]]
             self.gen_add_code_line("Rn[%d] = %s;" % (3 * rr + cc, " + ".join(terms) if terms else "static_cast<T>(0)"))
     if i > 0:
-        for rr in range(3):
-            terms = ["Rn[%d]*%s" % (3 * rr + k, C(r[k])) for k in range(3) if r[k] != 0.0]
-            if terms:
-                self.gen_add_code_line("pc[%d] -= %s;" % (rr, " + ".join(terms)))
+        if nseg == 1:
+            r = self.gen_tip_frame_joint_offset(i)
+            for rr in range(3):
+                terms = ["Rn[%d]*%s" % (3 * rr + k, C(r[k])) for k in range(3) if r[k] != 0.0]
+                if terms:
+                    self.gen_add_code_line("pc[%d] -= %s;" % (rr, " + ".join(terms)))
+        else:
+            self.gen_add_code_line("const T *rj = &grid_model_constants(static_cast<const T *>(nullptr))[%d + 4*%s]; // origin of that joint's frame in its parent's coordinates" % (54 * m.n + 12 * self.lanes_per_solve, J))
+            self.gen_add_code_line("#pragma unroll")
+            self.gen_add_code_line("for (int r = 0; r < 3; r++) { pc[r] -= Rn[3*r]*rj[0] + Rn[3*r+1]*rj[1] + Rn[3*r+2]*rj[2]; }")
         self.gen_add_code_line("#pragma unroll")
         self.gen_add_code_line("for (int r = 0; r < 9; r++) { Rc[r] = Rn[r]; }")
     elif with_gravity:
@@ -245,7 +268,7 @@ def _emit_link_setup(self, kinematics=True):
     self.gen_add_code_line("//")
     self.gen_add_code_line("// tip frame, lane j <-> joint j: joint axis, link inertia, velocity, bias acceleration / force, Coriolis matrix")
     self.gen_add_code_line("//")
-    self.gen_add_code_line("T mku[GRID_SCAN_STEPS], mkd[GRID_SCAN_STEPS]; grid_prefix_masks(mku, lane); grid_suffix_masks(mkd, lane);")
+    self.gen_add_code_line("T mku[GRID_SCAN_STEPS], mkd[GRID_SCAN_STEPS]; grid_prefix_masks(mku, pos); grid_suffix_masks(mkd, pos);")
     if kinematics:
         self.gen_add_code_line("const T qd = s_qd[lane]; // (lanes without a joint read a neighbouring finite value: their inertia is zero and nothing reads their prefix sums)")
     self.gen_add_code_line("T S[6];")
@@ -319,6 +342,18 @@ def _emit_bias(self, with_qdd):
     self.gen_add_code_line("grid_suffix_sum(IC, mkd); grid_suffix_sum(BC, mkd); grid_suffix_sum(fC, mkd); // composites over the links j..n-1")
 
 
+def _own_rows(self, dst_fmt, val_fmt, zero="static_cast<T>(0)"):
+    """Emit the n stores of one output column: rows of the lane's own chain take val_fmt % position, the others are structural zeros
+    (dst_fmt % row gives the lvalue).  One chain: every row is an own row."""
+    n, L, nseg = self.model.n, self.tip_L, self.tip_nseg
+    for row in range(n):
+        sr, kk = divmod(row, L)
+        if nseg == 1:
+            self.gen_add_code_line("%s = %s;" % (dst_fmt % row, val_fmt % kk))
+        else:
+            self.gen_add_code_line("%s = (seg == %d) ? %s : %s;" % (dst_fmt % row, sr, val_fmt % kk, zero))
+
+
 def _emit_assembly(self, s_G="s_G", dst="s_df_du", minv="s_Minv"):
     """Pdd, t1..t4, the [S | t1 | t4] hand-off and this lane's two columns of dc/du, then -Minv*dc/du into the staging area."""
     m = self.model
@@ -338,23 +373,24 @@ def _emit_assembly(self, s_G="s_G", dst="s_df_du", minv="s_Minv"):
     self.gen_add_end_control_flow()
     self.gen_add_sync(False)
     self.gen_add_code_line("// column `lane` of dc/dq and of dc/dqd: rows k <= lane use this lane's t3, t2 with S_k; rows k > lane use t1_k, t4_k with this lane's Pdd, Pd, S")
-    self.gen_add_code_line("T dq[%d], dqd[%d];" % (n, n))
+    L = self.tip_L
+    self.gen_add_code_line("T dq[%d], dqd[%d]; // rows of this lane's own chain (every other row of the column is structurally zero)" % (L, L))
     self.gen_add_code_line("#pragma unroll")
-    self.gen_add_code_line("for (int k = 0; k < %d; k++) {" % n, True)
+    self.gen_add_code_line("for (int k = 0; k < %d; k++) {" % L, True)
     self.gen_add_code_line("T g[16];")
     self.gen_add_code_line("#pragma unroll")
-    self.gen_add_code_line("for (int r = 0; r < 16; r++) { g[r] = %s[16*k + r]; }" % s_G)
+    self.gen_add_code_line("for (int r = 0; r < 16; r++) { g[r] = %s[16*(base + k) + r]; }" % s_G)
     self.gen_add_code_line("const T up_q = g[0]*t3[0] + g[1]*t3[1] + g[2]*t3[2] + g[3]*t3[3] + g[4]*t3[4] + g[5]*t3[5];")
     self.gen_add_code_line("const T up_d = g[0]*t2[0] + g[1]*t2[1] + g[2]*t2[2] + g[3]*t2[3] + g[4]*t2[4] + g[5]*t2[5];")
     self.gen_add_code_line("const T lo_q = g[6]*Pdd[0] + g[7]*Pdd[1] + g[8]*Pdd[2] + g[9]*Pdd[3] + g[10]*Pdd[4] + g[11]*Pdd[5] + g[12]*Pd[0] + g[13]*Pd[1] + g[14]*Pd[2];")
     self.gen_add_code_line("const T lo_d = static_cast<T>(2)*(g[6]*Pd[0] + g[7]*Pd[1] + g[8]*Pd[2] + g[9]*Pd[3] + g[10]*Pd[4] + g[11]*Pd[5]) + g[12]*S[0] + g[13]*S[1] + g[14]*S[2];")
-    self.gen_add_code_line("dq[k] = (k <= lane) ? up_q : lo_q;")
-    self.gen_add_code_line("dqd[k] = ((k <= lane) ? up_d : lo_d) + ((k == lane) ? Lc[10] : static_cast<T>(0)); // + damping on the diagonal (oracle _test.py:486)")
+    self.gen_add_code_line("dq[k] = (k <= pos) ? up_q : lo_q;")
+    self.gen_add_code_line("dqd[k] = ((k <= pos) ? up_d : lo_d) + ((k == pos) ? Lc[10] : static_cast<T>(0)); // + damping on the diagonal (oracle _test.py:486)")
     self.gen_add_end_control_flow()
     if minv is None:
         self.gen_add_code_line("if (lane < %d) {" % n, True)
-        self.gen_add_code_line("#pragma unroll")
-        self.gen_add_code_line("for (int row = 0; row < %d; row++) { %s[lane*%d + row] = dq[row]; %s[(%d + lane)*%d + row] = dqd[row]; }" % (n, dst, n, dst, n, n))
+        _own_rows(self, dst + "[lane*" + str(n) + " + %d]", "dq[%d]")
+        _own_rows(self, dst + "[(" + str(n) + " + lane)*" + str(n) + " + %d]", "dqd[%d]")
         self.gen_add_end_control_flow()
         return
     self.gen_add_code_line("// finally df/du = -Minv*dc/du for the two columns this lane owns (Minv is read wave-uniformly from LDS)")
@@ -363,7 +399,7 @@ def _emit_assembly(self, s_G="s_G", dst="s_df_du", minv="s_Minv"):
     self.gen_add_code_line("for (int row = 0; row < %d; row++) {" % n, True)
     self.gen_add_code_line("T vq = static_cast<T>(0), vd = static_cast<T>(0);")
     self.gen_add_code_line("#pragma unroll")
-    self.gen_add_code_line("for (int i = 0; i < %d; i++) { const T mi = %s[row*%d + i]; vq += mi*dq[i]; vd += mi*dqd[i]; }" % (n, minv, ld))
+    self.gen_add_code_line("for (int i = 0; i < %d; i++) { const T mi = %s[row*%d + base + i]; vq += mi*dq[i]; vd += mi*dqd[i]; }" % (L, minv, ld))
     self.gen_add_code_line("%s[lane*%d + row] = -vq; %s[(%d + lane)*%d + row] = -vd;" % (dst, n, dst, n, n))
     self.gen_add_end_control_flow()
     self.gen_add_end_control_flow()
@@ -375,14 +411,21 @@ def _emit_link_constants_load(self):
     self.gen_add_code_line("{ const T *d_L = &grid_model_constants(static_cast<const T *>(nullptr))[%d + 12*lane]; (void)d_robotModel;" % (54 * n))
     self.gen_add_code_line("  #pragma unroll")
     self.gen_add_code_line("  for (int r = 0; r < 12; r++) { Lc[r] = d_L[r]; } }")
+    L, nseg = self.tip_L, self.tip_nseg
+    if nseg == 1:
+        self.gen_add_code_line("const int base = 0, pos = lane; // one chain: position in the chain == lane")
+    else:
+        self.gen_add_code_line("const int seg = lane / %d; // %d chains of %d joints side by side: chain of this lane's joint, its first joint, the position inside it" % (L, nseg, L))
+        self.gen_add_code_line("const int base = %d*((seg < %d) ? seg : %d), pos = lane - base; // (lanes without a joint follow the last chain with pos >= %d: they match no step)" % (L, nseg, nseg - 1, L))
 
 
 def _emit_ldl_factor(self, A="A", U="Uf", rd="rd"):
     """In-register U D U^T factorisation of the symmetric n x n matrix A (upper triangle A[i][j], i <= j), eliminating the tip joint
     first: A = Uf diag(1/rd) Uf^T with Uf unit upper triangular.  Wave-uniform (every lane factors the same matrix): n reciprocals,
     n(n-1)/2 multiplies, (n-1)n(n+1)/6 FMAs and no cross-lane traffic.  Diagonal scaling does not affect an unpivoted symmetric
-    factorisation, so the badly scaled joint-space inertia (1e-3 at the wrist, 10 at the base) is harmless."""
-    n = self.model.n
+    factorisation, so the badly scaled joint-space inertia (1e-3 at the wrist, 10 at the base) is harmless.
+    (Forests: n is the chain length and the matrix is the lane's own diagonal block.)"""
+    n = self.tip_L
     for k in range(n - 1, 0, -1):
         self.gen_add_code_line("const T %s%d = grid_rcp(%s%d_%d);" % (rd, k, A, k, k))
         self.gen_add_code_line(" ".join("const T %s%d_%d = %s%d_%d*%s%d;" % (U, i, k, A, i, k, rd, k) for i in range(k)))
@@ -393,7 +436,7 @@ def _emit_ldl_factor(self, A="A", U="Uf", rd="rd"):
 
 def _emit_ldl_solve(self, b, U="Uf", rd="rd"):
     """b <- A^-1 b for the register vector b[n] with the factors of _emit_ldl_factor: Uf y = b, z = y/D, Uf^T x = z."""
-    n = self.model.n
+    n = self.tip_L
     for k in range(n - 1, 0, -1):
         self.gen_add_code_line(" ".join("%s[%d] -= %s%d_%d*%s[%d];" % (b, i, U, i, k, b, k) for i in range(k)))
     self.gen_add_code_line(" ".join("%s[%d] *= %s%d;" % (b, k, rd, k) for k in range(n)))
@@ -432,8 +475,9 @@ def gen_forward_dynamics_gradient_inner_tip(self, use_thread_group=False, use_qd
     _emit_link_constants_load(self)
     _emit_chain_decls(self)
     import os
-    chain_lds = (not use_qdd_Minv_input) and os.environ.get("GRID_TIP_CHAIN", "select") == "lds"
-    for i in range(n - 1, -1, -1):
+    chain_lds = (not use_qdd_Minv_input) and self.tip_nseg == 1 and os.environ.get("GRID_TIP_CHAIN", "select") == "lds"
+    L = self.tip_L
+    for i in range(L - 1, -1, -1):
         _chain_step(self, i, "s_G" if chain_lds else None)
     if chain_lds:
         self.gen_add_sync(use_thread_group)
@@ -477,39 +521,40 @@ def gen_forward_dynamics_gradient_inner_tip(self, use_thread_group=False, use_qd
         return
     self.gen_add_code_line("// pass 1 over the records: column `lane` of M (rows k <= lane), column `lane` of dc/dqd (complete: it does not depend on qdd),")
     self.gen_add_code_line("// the qdd-independent part of the rows k > lane of dc/dq, and tau - c of every joint")
-    self.gen_add_code_line("T dq[%d], dqd[%d], rhs[%d], Mcol[%d];" % (n, n, n, ld))
-    for k in range(n, ld):
+    Lp = (L + 3) // 4 * 4
+    self.gen_add_code_line("T dq[%d], dqd[%d], rhs[%d], Mcol[%d]; // rows of this lane's own chain" % (L, L, L, Lp))
+    for k in range(L, Lp):
         self.gen_add_code_line("Mcol[%d] = static_cast<T>(0);" % k)
     self.gen_add_code_line("#pragma unroll")
-    self.gen_add_code_line("for (int k = 0; k < %d; k++) {" % n, True)
+    self.gen_add_code_line("for (int k = 0; k < %d; k++) {" % L, True)
     self.gen_add_code_line("T g[16];")
     self.gen_add_code_line("#pragma unroll")
-    self.gen_add_code_line("for (int r = 0; r < 16; r++) { g[r] = s_G[16*k + r]; }")
+    self.gen_add_code_line("for (int r = 0; r < 16; r++) { g[r] = s_G[16*(base + k) + r]; }")
     self.gen_add_code_line("const T mkj  = g[0]*t1[0] + g[1]*t1[1] + g[2]*t1[2] + g[3]*t1[3] + g[4]*t1[4] + g[5]*t1[5];")
     self.gen_add_code_line("const T up_d = g[0]*t2[0] + g[1]*t2[1] + g[2]*t2[2] + g[3]*t2[3] + g[4]*t2[4] + g[5]*t2[5];")
     self.gen_add_code_line("const T lo_d = static_cast<T>(2)*(g[6]*Pd[0] + g[7]*Pd[1] + g[8]*Pd[2] + g[9]*Pd[3] + g[10]*Pd[4] + g[11]*Pd[5]) + g[12]*S[0] + g[13]*S[1] + g[14]*S[2];")
     self.gen_add_code_line("dq[k] = g[12]*Pd[0] + g[13]*Pd[1] + g[14]*Pd[2];")
-    self.gen_add_code_line("dqd[k] = ((k <= lane) ? up_d : lo_d) + ((k == lane) ? Lc[10] : static_cast<T>(0)); // + damping on the diagonal (oracle _test.py:486)")
+    self.gen_add_code_line("dqd[k] = ((k <= pos) ? up_d : lo_d) + ((k == pos) ? Lc[10] : static_cast<T>(0)); // + damping on the diagonal (oracle _test.py:486)")
     self.gen_add_code_line("rhs[k] = g[15];")
     self.gen_add_code_line("Mcol[k] = mkj; // (rows k > lane are never read)")
     self.gen_add_end_control_flow()
     self.gen_add_code_line("if (lane < %d) {" % n, True)
     self.gen_add_code_line("#pragma unroll")
-    self.gen_add_code_line("for (int k = 0; k < %d; k++) { s_M[%d*lane + k] = Mcol[k]; }" % (ld, ld))
+    self.gen_add_code_line("for (int k = 0; k < %d; k++) { s_M[%d*lane + k] = Mcol[k]; }" % (Lp, ld))
     self.gen_add_end_control_flow()
     self.gen_add_sync(use_thread_group)
-    self.gen_add_code_line("// the joint-space inertia, wave-uniform: upper triangle A<i>_<j> = M[i][j], i <= j  (column j was written by lane j)")
-    for j in range(n):
-        self.gen_add_code_line(" ".join("T A%d_%d = s_M[%d];" % (i, j, ld * j + i) for i in range(j + 1)))
+    self.gen_add_code_line("// the joint-space inertia (of this lane's chain), uniform over the chain's lanes: upper triangle A<i>_<j> = M[i][j], i <= j  (column j was written by the lane of joint j)")
+    for j in range(L):
+        self.gen_add_code_line(" ".join("T A%d_%d = s_M[%d*(base + %d) + %d];" % (i, j, ld, j, i) for i in range(j + 1)))
     _emit_ldl_factor(self)
     self.gen_add_code_line("// qdd = M^-1 (tau - c); this lane keeps the entry of its own joint")
     _emit_ldl_solve(self, "rhs")
     sel = "rhs[0]"
-    for k in range(1, n):
-        sel = "((lane == %d) ? rhs[%d] : %s)" % (k, k, sel)
+    for k in range(1, L):
+        sel = "((pos == %d) ? rhs[%d] : %s)" % (k, k, sel)
     self.gen_add_code_line("const T qdd = (lane < %d) ? %s : static_cast<T>(0);" % (n, sel))
     if stop == 7:
-        self.gen_add_code_line("if (lane < %d) { s_df_du[lane] = qdd + %s; }" % (n, " + ".join("dq[%d] + dqd[%d]" % (k, k) for k in range(n))))
+        self.gen_add_code_line("if (lane < %d) { s_df_du[lane] = qdd + %s; }" % (n, " + ".join("dq[%d] + dqd[%d]" % (k, k) for k in range(L))))
         self.gen_add_end_function()
         return
     self.gen_add_code_line("// the acceleration-dependent parts: a += sum over the ancestors of S_k qdd_k, f^C += sum over the subtree of I_k da_k")
@@ -526,20 +571,24 @@ def gen_forward_dynamics_gradient_inner_tip(self, use_thread_group=False, use_qd
     self.gen_add_code_line("T t3[6]; grid_bmul(t3, BC, Pd); grid_rbi_mul_peq(t3, IC, Pdd, static_cast<T>(1)); grid_fxv_peq(t3, S, fC);")
     self.gen_add_code_line("// pass 2 over the records: column `lane` of dc/dq")
     self.gen_add_code_line("#pragma unroll")
-    self.gen_add_code_line("for (int k = 0; k < %d; k++) {" % n, True)
+    self.gen_add_code_line("for (int k = 0; k < %d; k++) {" % L, True)
     self.gen_add_code_line("T g[12];")
     self.gen_add_code_line("#pragma unroll")
-    self.gen_add_code_line("for (int r = 0; r < 12; r++) { g[r] = s_G[16*k + r]; }")
+    self.gen_add_code_line("for (int r = 0; r < 12; r++) { g[r] = s_G[16*(base + k) + r]; }")
     self.gen_add_code_line("const T up_q = g[0]*t3[0] + g[1]*t3[1] + g[2]*t3[2] + g[3]*t3[3] + g[4]*t3[4] + g[5]*t3[5];")
     self.gen_add_code_line("const T lo_q = g[6]*Pdd[0] + g[7]*Pdd[1] + g[8]*Pdd[2] + g[9]*Pdd[3] + g[10]*Pdd[4] + g[11]*Pdd[5] + dq[k];")
-    self.gen_add_code_line("dq[k] = (k <= lane) ? up_q : lo_q;")
+    self.gen_add_code_line("dq[k] = (k <= pos) ? up_q : lo_q;")
     self.gen_add_end_control_flow()
     self.gen_add_code_line("// df/du = -M^-1 dc/du for the two columns this lane owns")
     _emit_ldl_solve(self, "dq")
     _emit_ldl_solve(self, "dqd")
     self.gen_add_code_line("if (lane < %d) {" % n, True)
-    self.gen_add_code_line("#pragma unroll")
-    self.gen_add_code_line("for (int row = 0; row < %d; row++) { s_df_du[lane*%d + row] = -dq[row]; s_df_du[(%d + lane)*%d + row] = -dqd[row]; }" % (n, n, n, n))
+    if self.tip_nseg == 1:
+        self.gen_add_code_line("#pragma unroll")
+        self.gen_add_code_line("for (int row = 0; row < %d; row++) { s_df_du[lane*%d + row] = -dq[row]; s_df_du[(%d + lane)*%d + row] = -dqd[row]; }" % (n, n, n, n))
+    else:
+        _own_rows(self, "s_df_du[lane*" + str(n) + " + %d]", "-dq[%d]")
+        _own_rows(self, "s_df_du[(" + str(n) + " + lane)*" + str(n) + " + %d]", "-dqd[%d]")
     self.gen_add_end_control_flow()
     self.gen_add_end_function()
 
@@ -568,6 +617,8 @@ def _emit_force_only(self, with_qdd):
 def _emit_mass_matrix_factor(self, use_thread_group, rhs_expr=None):
     """IC -> t1 = I^C S, record [S | t1 | . | rhs], M column by dots, hand-off, wave-uniform factorisation (leaves Uf*, rd*; rhs[] if asked)."""
     n = self.model.n
+    L = self.tip_L
+    Lp = (L + 3) // 4 * 4
     ld = self.minv_ld
     self.gen_add_code_line("T t1[6]; grid_rbi_mul(t1, IC, S);")
     self.gen_add_code_line("if (lane < %d) {" % n, True)
@@ -578,25 +629,25 @@ def _emit_mass_matrix_factor(self, use_thread_group, rhs_expr=None):
         self.gen_add_code_line("rec[6] = %s;" % rhs_expr)
     self.gen_add_end_control_flow()
     self.gen_add_sync(use_thread_group)
-    self.gen_add_code_line("T Mcol[%d]%s;" % (ld, (", rhs[%d]" % n) if rhs_expr is not None else ""))
-    for k in range(n, ld):
+    self.gen_add_code_line("T Mcol[%d]%s;" % (Lp, (", rhs[%d]" % L) if rhs_expr is not None else ""))
+    for k in range(L, Lp):
         self.gen_add_code_line("Mcol[%d] = static_cast<T>(0);" % k)
     self.gen_add_code_line("#pragma unroll")
-    self.gen_add_code_line("for (int k = 0; k < %d; k++) { // M[k][lane] = S_k . (I^C_lane S_lane), rows k <= lane" % n, True)
+    self.gen_add_code_line("for (int k = 0; k < %d; k++) { // M[k][lane] = S_k . (I^C_lane S_lane), rows k <= lane of the lane's own chain" % L, True)
     self.gen_add_code_line("T g[8];")
     self.gen_add_code_line("#pragma unroll")
-    self.gen_add_code_line("for (int r = 0; r < 8; r++) { g[r] = s_G[16*k + r]; }")
+    self.gen_add_code_line("for (int r = 0; r < 8; r++) { g[r] = s_G[16*(base + k) + r]; }")
     self.gen_add_code_line("Mcol[k] = g[0]*t1[0] + g[1]*t1[1] + g[2]*t1[2] + g[3]*t1[3] + g[4]*t1[4] + g[5]*t1[5];")
     if rhs_expr is not None:
         self.gen_add_code_line("rhs[k] = g[6];")
     self.gen_add_end_control_flow()
     self.gen_add_code_line("if (lane < %d) {" % n, True)
     self.gen_add_code_line("#pragma unroll")
-    self.gen_add_code_line("for (int k = 0; k < %d; k++) { s_M[%d*lane + k] = Mcol[k]; }" % (ld, ld))
+    self.gen_add_code_line("for (int k = 0; k < %d; k++) { s_M[%d*lane + k] = Mcol[k]; }" % (Lp, ld))
     self.gen_add_end_control_flow()
     self.gen_add_sync(use_thread_group)
-    for j in range(n):
-        self.gen_add_code_line(" ".join("T A%d_%d = s_M[%d];" % (i, j, ld * j + i) for i in range(j + 1)))
+    for j in range(L):
+        self.gen_add_code_line(" ".join("T A%d_%d = s_M[%d*(base + %d) + %d];" % (i, j, ld, j, i) for i in range(j + 1)))
     _emit_ldl_factor(self)
 
 
@@ -608,7 +659,7 @@ def _tip_inner_header(self, name, doc, notes, params, sig, with_gravity=True):
     self.gen_add_code_line("void %s(%s, const robotModel<T> *d_robotModel, const int lane) {" % (name, sig), True)
     _emit_link_constants_load(self)
     _emit_chain_decls(self)
-    for i in range(self.model.n - 1, -1, -1):
+    for i in range(self.tip_L - 1, -1, -1):
         _chain_step(self, i, None, with_gravity)
 
 
@@ -659,8 +710,8 @@ def gen_forward_dynamics_inner_tip(self, use_thread_group=False):
     _emit_mass_matrix_factor(self, use_thread_group, rhs_expr="s_u[lane] - (grid_dot6(S, fC) + Lc[10]*qd)")
     _emit_ldl_solve(self, "rhs")
     sel = "rhs[0]"
-    for k in range(1, n):
-        sel = "((lane == %d) ? rhs[%d] : %s)" % (k, k, sel)
+    for k in range(1, self.tip_L):
+        sel = "((pos == %d) ? rhs[%d] : %s)" % (k, k, sel)
     self.gen_add_code_line("if (lane < %d) { s_qdd[lane] = %s; }" % (n, sel))
     self.gen_add_end_function()
 
@@ -681,14 +732,14 @@ def gen_direct_minv_inner_tip(self, use_thread_group=False):
     self.gen_add_code_line("for (int r = 0; r < 10; r++) { IC[r] = I[r]; }")
     self.gen_add_code_line("grid_suffix_sum(IC, mkd);")
     _emit_mass_matrix_factor(self, use_thread_group)
-    self.gen_add_code_line("T x[%d];" % n)
+    L = self.tip_L
+    self.gen_add_code_line("T x[%d];" % L)
     self.gen_add_code_line("#pragma unroll")
-    self.gen_add_code_line("for (int k = 0; k < %d; k++) { x[k] = (k == lane) ? static_cast<T>(1) : static_cast<T>(0); }" % n)
+    self.gen_add_code_line("for (int k = 0; k < %d; k++) { x[k] = (k == pos) ? static_cast<T>(1) : static_cast<T>(0); }" % L)
     _emit_ldl_solve(self, "x")
     self.gen_add_sync(use_thread_group)  # every lane has read M before the same slot receives M^-1
     self.gen_add_code_line("if (lane < %d) {" % n, True)
-    self.gen_add_code_line("#pragma unroll")
-    self.gen_add_code_line("for (int k = 0; k < %d; k++) { s_Minv[%d*lane + k] = x[k]; }" % (n, ld))
+    _own_rows(self, "s_Minv[" + str(ld) + "*lane + %d]", "x[%d]")
     self.gen_add_end_control_flow()
     self.gen_add_code_line("(void)gvec; (void)mku;")
     self.gen_add_end_function()
