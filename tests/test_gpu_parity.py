@@ -226,7 +226,37 @@ def test_generated_host_api_float_and_double(torch_cuda, golden, tmp_path):
         assert float(line.split("=")[-1]) <= (1e-4 if line.startswith("float") else 1e-9), line
 
 
-@pytest.mark.parametrize("env", [{"GRID_GRADIENT_WALK": "lds"}, {"GRID_COLS_PER_LANE": "1"}])
+@pytest.mark.parametrize("name", ["iiwa14", "arm6", "hyq"])
+def test_fd_grad_on_ill_conditioned_configurations(name, torch_cuda, libs):
+    """Edge cases of the domain: joint angles that line up every other joint axis (the worst conditioned joint-space inertia a chain
+    has), a wide input range, and the worst state a 10^6-state random sweep found for the tip-frame path (tools/parity_sweep.py:
+    4.5e-5 of max|df/du| near a shoulder + wrist alignment of the 7-DoF arm).  The acceptance bar is the same 1e-4."""
+    from oracle.rbd_oracle import Oracle
+
+    robot = RobotModel.from_fixture(name)
+    n = robot.n
+    lib = libs(name)
+    rng = np.random.default_rng(11)
+    N = 4096
+    x = inputs(n, N, seed=5)
+    x[:, 1:n:2] = rng.uniform(-0.02, 0.02, (N, len(range(1, n, 2)))).astype(np.float32)
+    x[: N // 8, 1:n:2] = 0.0  # exactly aligned
+    wide = np.hstack([rng.uniform(-10 * np.pi, 10 * np.pi, (N, n)), rng.uniform(-10, 10, (N, n)), rng.uniform(-100, 100, (N, n))]).astype(np.float32)
+    cases = [x, wide]
+    if name == "iiwa14":
+        cases.append(np.array([[-1.9726811647415161, -0.15061229467391968, 3.0075197219848633, -1.6245150566101074, 0.2933456301689148, -0.012131131254136562,
+                                -0.5525374412536621, -1.6120431423187256, -1.4713057279586792, -1.4227734804153442, 1.8603541851043701, 0.7642495632171631,
+                                0.44305285811424255, -1.240814447402954, -6.242157936096191, -5.802548885345459, 8.430603981018066, -4.893815517425537,
+                                7.717841625213623, -4.148682594299316, -4.838983535766602]], dtype=np.float32))
+    orc = Oracle(robot)
+    for xs in cases:
+        out = run_fd_grad(torch_cuda, lib, xs)
+        ref, _ = orc.fd_grad_batch(xs.astype(np.float64))
+        assert np.isfinite(out).all()
+        assert per_solve_err(out, ref) <= TOL
+
+
+@pytest.mark.parametrize("env", [{"GRID_GRADIENT_WALK": "lds"}, {"GRID_COLS_PER_LANE": "1"}, {"GRID_GRADIENT_WALK": "registers"}])
 def test_non_default_generation_variants_on_gpu(env, torch_cuda, golden, tmp_path):
     """The generated forms that the shipped fixtures do not select by default (LDS-assisted forward accumulation for deep trees,
     one derivative column per lane) are exercised on real wave64 hardware too: their LDS hand-offs rely on in-order LDS execution."""

@@ -1,0 +1,40 @@
+#!/usr/bin/env python3
+"""Large randomized parity sweep of forward_dynamics_gradient on the GPU against the fp64 C oracle (test infrastructure, oracle/).
+usage: python tools/parity_sweep.py [robot ...]   prints one JSON line per (robot, input distribution)."""
+import json, sys
+sys.path.insert(0, ".")
+import numpy as np, torch
+from gridcodegenerator_amd import RobotModel
+from gridcodegenerator_amd.runtime import load
+from oracle.rbd_oracle import Oracle
+
+import os
+robots = sys.argv[1:] or ["iiwa14", "arm6", "hyq", "chain12"]
+BUILD_DIR = os.environ.get("GRID_SWEEP_BUILD_DIR")  # experimental build to sweep instead of the shipped one
+DISTS = {"bench (q +-pi, qd +-2, u +-10)": (np.pi, 2.0, 10.0), "wide (q +-10pi, qd +-10, u +-100)": (10 * np.pi, 10.0, 100.0),
+         "aligned axes (bench, every other joint angle within +-0.02 rad of 0)": (np.pi, 2.0, 10.0)}
+for name in robots:
+    robot = RobotModel.from_fixture(name); n = robot.n
+    N, chunks = 65536, (16 if n <= 7 else 4)
+    lib = load(name, max_timesteps=N, build_dir=BUILD_DIR)
+    orc = Oracle(robot)
+    for label, (aq, aqd, au) in DISTS.items():
+        worst, worst_state, total = 0.0, None, 0
+        errs = []
+        for c in range(chunks):
+            rng = np.random.default_rng(1000 + c)
+            x = np.hstack([rng.uniform(-aq, aq, (N, n)), rng.uniform(-aqd, aqd, (N, n)), rng.uniform(-au, au, (N, n))]).astype(np.float32)
+            if label.startswith("aligned"):  # consecutive-but-one joint axes (nearly) parallel: the worst conditioned joint-space inertia a chain has
+                x[:, 1:n:2] = rng.uniform(-0.02, 0.02, (N, len(range(1, n, 2)))).astype(np.float32)
+            d_in = torch.from_numpy(x).cuda(); d_out = torch.empty((N, 2 * n * n), dtype=torch.float32, device="cuda")
+            lib.forward_dynamics_gradient_device(d_in, N, d_out, stream=torch.cuda.current_stream().cuda_stream)
+            torch.cuda.synchronize()
+            got = d_out.cpu().numpy().astype(np.float64)
+            ref, _ = orc.fd_grad_batch(x.astype(np.float64))
+            e = np.abs(got - ref).max(axis=1) / np.abs(ref).max(axis=1)
+            errs.append(e); total += N
+            if e.max() > worst:
+                worst, worst_state = float(e.max()), x[int(e.argmax())].tolist()
+        e = np.concatenate(errs)
+        print(json.dumps({"robot": name, "inputs": label, "states": total, "max_rel_err": worst, "p999": float(np.quantile(e, 0.999)), "median": float(np.median(e)),
+                          "over_1e-4": int((e > 1e-4).sum()), "over_2e-5": int((e > 2e-5).sum()), "worst_state": worst_state}), flush=True)
