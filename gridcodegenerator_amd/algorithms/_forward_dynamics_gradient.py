@@ -30,7 +30,7 @@ def gen_forward_dynamics_gradient_inner_python(self, use_thread_group=False, use
     n = self.model.n
     import os
     stop = int(os.environ.get("GRID_DEBUG_STOP", "0"))  # timing ablation only (results are wrong when set): 1 = X update, 2 = +Minv, 3 = +RNEA/qdd, 4 = +gradient walk
-    if self.tip_frame and stop in (0, 5, 6, 7):  # serial revolute chains: everything after the X update is one fused inner in the tip link's frame
+    if self.tip_frame and stop in (0, 5, 6, 7, 20):  # serial revolute chains: everything after the X update is one fused inner in the tip link's frame
         self.gen_forward_dynamics_gradient_inner_tip_function_call(use_thread_group, use_qdd_Minv_input, s_df_du_name)
         return
     if stop == 1:

@@ -472,9 +472,18 @@ def gen_forward_dynamics_gradient_inner_tip(self, use_thread_group=False, use_qd
     self.gen_add_code_line("template <typename T>")
     self.gen_add_code_line("__device__ __forceinline__")
     self.gen_add_code_line("void %s(%s) {" % (name, sig), True)
+    import os
+    ts_mode = (not use_qdd_Minv_input) and os.environ.get("GRID_DEBUG_STOP", "0") == "20"  # profiling build: per-wave cycle stamps at the phase boundaries replace the first 8 outputs
+
+    def TS(i):
+        if ts_mode:
+            self.gen_add_code_line("asm volatile(\"s_waitcnt vmcnt(0) lgkmcnt(0)\\n\\ts_memtime %%0\\n\\ts_waitcnt lgkmcnt(0)\" : \"=s\"(grid_ts[%d]) : : \"memory\");" % i)
+
+    if ts_mode:
+        self.gen_add_code_line("unsigned long long grid_ts[8];")
+    TS(0)
     _emit_link_constants_load(self)
     _emit_chain_decls(self)
-    import os
     chain_lds = (not use_qdd_Minv_input) and self.tip_nseg == 1 and os.environ.get("GRID_TIP_CHAIN", "select") == "lds"
     L = self.tip_L
     for i in range(L - 1, -1, -1):
@@ -501,6 +510,9 @@ def gen_forward_dynamics_gradient_inner_tip(self, use_thread_group=False, use_qd
         self.gen_add_code_line("if (lane < %d) { s_df_du[lane] = myR[0] + myp[0] + gvec[0] + Lc[0]; }" % n)
         self.gen_add_end_function()
         return
+    if ts_mode:
+        self.gen_add_code_line("grid_pin(myR[0]); grid_pin(myp[0]); grid_pin(gvec[0]);")
+    TS(1)
     _emit_link_setup(self)
     _emit_bias(self, False)
     self.gen_add_code_line("// everything that does not depend on qdd: t1, t2, t4, the bias force; one hand-off record per joint: [S | t1 | t4 | tau - c]")
@@ -515,6 +527,7 @@ def gen_forward_dynamics_gradient_inner_tip(self, use_thread_group=False, use_qd
     self.gen_add_code_line("rec[12] = t4[0]; rec[13] = t4[1]; rec[14] = t4[2]; rec[15] = s_u[lane] - (grid_dot6(S, fC) + Lc[10]*qd);")
     self.gen_add_end_control_flow()
     self.gen_add_sync(use_thread_group)
+    TS(2)
     if stop == 6:
         self.gen_add_code_line("if (lane < %d) { s_df_du[lane] = s_G[16*lane + 15] + t2[0] + t2[1] + t2[2] + t2[3] + t2[4] + t2[5]; }" % n)
         self.gen_add_end_function()
@@ -543,6 +556,7 @@ def gen_forward_dynamics_gradient_inner_tip(self, use_thread_group=False, use_qd
     self.gen_add_code_line("for (int k = 0; k < %d; k++) { s_M[%d*lane + k] = Mcol[k]; }" % (Lp, ld))
     self.gen_add_end_control_flow()
     self.gen_add_sync(use_thread_group)
+    TS(3)
     self.gen_add_code_line("// the joint-space inertia (of this lane's chain), uniform over the chain's lanes: upper triangle A<i>_<j> = M[i][j], i <= j  (column j was written by the lane of joint j)")
     for j in range(L):
         self.gen_add_code_line(" ".join("T A%d_%d = s_M[%d*(base + %d) + %d];" % (i, j, ld, j, i) for i in range(j + 1)))
@@ -553,6 +567,9 @@ def gen_forward_dynamics_gradient_inner_tip(self, use_thread_group=False, use_qd
     for k in range(1, L):
         sel = "((pos == %d) ? rhs[%d] : %s)" % (k, k, sel)
     self.gen_add_code_line("const T qdd = (lane < %d) ? %s : static_cast<T>(0);" % (n, sel))
+    if ts_mode:
+        self.gen_add_code_line("{ T qp = qdd; grid_pin(qp); }")
+    TS(4)
     if stop == 7:
         self.gen_add_code_line("if (lane < %d) { s_df_du[lane] = qdd + %s; }" % (n, " + ".join("dq[%d] + dqd[%d]" % (k, k) for k in range(L))))
         self.gen_add_end_function()
@@ -582,6 +599,9 @@ def gen_forward_dynamics_gradient_inner_tip(self, use_thread_group=False, use_qd
     self.gen_add_code_line("// df/du = -M^-1 dc/du for the two columns this lane owns")
     _emit_ldl_solve(self, "dq")
     _emit_ldl_solve(self, "dqd")
+    if ts_mode:
+        self.gen_add_code_line("grid_pin(dq[0]); grid_pin(dqd[0]);")
+    TS(5)
     self.gen_add_code_line("if (lane < %d) {" % n, True)
     if self.tip_nseg == 1:
         self.gen_add_code_line("#pragma unroll")
@@ -590,6 +610,13 @@ def gen_forward_dynamics_gradient_inner_tip(self, use_thread_group=False, use_qd
         _own_rows(self, "s_df_du[lane*" + str(n) + " + %d]", "-dq[%d]")
         _own_rows(self, "s_df_du[(" + str(n) + " + lane)*" + str(n) + " + %d]", "-dqd[%d]")
     self.gen_add_end_control_flow()
+    if ts_mode:
+        self.gen_add_sync(use_thread_group)
+        TS(6)
+        self.gen_add_code_line("if (lane == 0) { // cycles since the inner function was entered at each boundary; [7] = low 24 bits of the entry stamp, [8] = hardware id")
+        self.gen_add_code_line("    for (int i = 1; i < 7; i++) { s_df_du[i] = static_cast<T>(static_cast<float>(grid_ts[i] - grid_ts[0])); }")
+        self.gen_add_code_line("    s_df_du[0] = static_cast<T>(0); s_df_du[7] = static_cast<T>(static_cast<float>(grid_ts[0] & 0xFFFFFFull));")
+        self.gen_add_code_line("    s_df_du[8] = static_cast<T>(static_cast<float>(__builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11)) & 0xFFFFFF)); }")
     self.gen_add_end_function()
 
 
