@@ -1,0 +1,38 @@
+"""The second-order oracle (oracle/idsva_so_oracle.py) restates the reference's idsva_so emitter; the reference holds no vectors for it
+(parity unpinned), so it is anchored on central differences of the PINNED first-order oracle (rbd_rnea_grad, rbd_minv of oracle/rbd_oracle.c)."""
+import numpy as np
+import pytest
+
+from gridcodegenerator_amd import RobotModel
+from gridcodegenerator_amd.robot import DuckRobot
+from oracle.idsva_so_oracle import idsva_so
+from oracle.rbd_oracle import Oracle
+
+
+def finite_difference_tensors(orc, n, q, qd, qdd, h=1e-5):
+    dq2, dqd2, dvdq, dMdq = (np.zeros((n, n, n)) for _ in range(4))
+    for k in range(n):
+        e = np.zeros(n)
+        e[k] = h
+        d = (orc.rnea_grad(q + e, qd, qdd) - orc.rnea_grad(q - e, qd, qdd)) / (2 * h)   # d/dq_k of [dtau/dq | dtau/dqd]
+        dq2[:, :, k] = d[:, :n]
+        dvdq[:, k, :] = d[:, n:]                                                       # [i][j=k][l] = d^2 tau_i / dq_k dqd_l
+        d = (orc.rnea_grad(q, qd + e, qdd) - orc.rnea_grad(q, qd - e, qdd)) / (2 * h)
+        dqd2[:, :, k] = d[:, n:]
+        dMdq[:, k, :] = (np.linalg.inv(orc.minv(q + e)) - np.linalg.inv(orc.minv(q - e))) / (2 * h)  # [i][j=k][l] = d M_il / dq_k
+    return dq2, dqd2, dvdq, dMdq
+
+
+@pytest.mark.parametrize("name", ["iiwa14", "arm6", "hyq"])
+def test_second_order_oracle_matches_finite_differences_of_the_first_order_oracle(name):
+    rm = RobotModel.from_fixture(name)
+    m = DuckRobot(rm)
+    n = m.n
+    orc = Oracle(rm)
+    rng = np.random.default_rng(3)
+    for _ in range(2):
+        q, qd, qdd = rng.uniform(-np.pi, np.pi, n), rng.uniform(-2, 2, n), rng.uniform(-5, 5, n)
+        got = idsva_so(m, q, qd, qdd)
+        ref = finite_difference_tensors(orc, n, q, qd, qdd)
+        for a, b in zip(got, ref):
+            assert np.abs(a - b).max() <= 1e-7 * max(np.abs(b).max(), 1.0)
