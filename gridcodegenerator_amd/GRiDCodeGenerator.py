@@ -35,6 +35,7 @@ class GRiDCodeGenerator:
         gen_forward_dynamics_inner_function_call, gen_forward_dynamics_inner, gen_forward_dynamics_device, gen_forward_dynamics_kernel, \
         gen_forward_dynamics_host, gen_forward_dynamics, \
         gen_aba_inner_temp_mem_size, gen_aba_inner_function_call, gen_aba_inner, gen_aba_device, gen_aba_kernel, gen_aba_host, gen_aba, \
+        gen_idsva_so_available, gen_idsva_so_inner_temp_mem_size, gen_idsva_so_inner_function_call, gen_idsva_so_inner, gen_idsva_so_device, gen_idsva_so_kernel, gen_idsva_so_host, gen_idsva_so, \
         gen_inverse_dynamics_gradient_inner_temp_mem_size, gen_inverse_dynamics_gradient_kernel_max_temp_mem_size, \
         gen_inverse_dynamics_gradient_inner_function_call, gen_inverse_dynamics_gradient_inner, gen_dc_du_to_lds, gen_gradient_slots, gen_gradient_outputs_decl, \
         gen_inverse_dynamics_gradient_device, gen_inverse_dynamics_gradient_kernel, gen_inverse_dynamics_gradient_host, gen_inverse_dynamics_gradient, \
@@ -158,11 +159,12 @@ class GRiDCodeGenerator:
                                  "// the *_DYNAMIC_SHARED_MEM_COUNT constants below are that amount for SUGGESTED_THREADS"])
         for k in ("IN", "X", "U", "T", "MINV", "QDD", "F", "J"):
             self.gen_add_code_line("const int GRID_OFF_" + k + " = " + str(lds[k]) + ";")
-        for k in ("ID", "MINV", "FD", "ABA", "ID_DU", "FD_DU"):
+        for k in ("ID", "MINV", "FD", "ABA", "ID_DU", "FD_DU", "IDSVA_SO"):
             self.gen_add_code_line("const int " + k + "_DYNAMIC_SHARED_MEM_COUNT = " + str(count) + ";")
         self.gen_add_code_lines(["const int ID_DU_MAX_SHARED_MEM_COUNT = " + str(count) + ";",
                                  "const int FD_DU_MAX_SHARED_MEM_COUNT = " + str(count) + ";",
                                  "// (reference bookkeeping) derivative columns that are structurally non-zero: dv/da " + str(dva_cols) + ", df " + str(df_cols)])
+        self.gen_add_code_line("#define GRID_HAS_IDSVA_SO %d // the second-order inverse-dynamics derivatives are emitted for serial revolute chains" % (1 if self.gen_idsva_so_available() else 0))
         self.gen_add_code_line("// Define custom structs")
         self.gen_add_code_lines(["template <typename T>", "struct robotModel {", "    T *d_XImats;", "    int *d_topology_helpers;", "};"])
         self.gen_add_code_lines(["template <typename T>", "struct gridData {",
@@ -180,6 +182,10 @@ class GRiDCodeGenerator:
         host = [("h_q_qd_u", "3*NUM_JOINTS"), ("h_q_qd", "2*NUM_JOINTS"), ("h_q", "NUM_JOINTS"), ("h_c", "NUM_JOINTS"),
                 ("h_Minv", "NUM_JOINTS*NUM_JOINTS"), ("h_qdd", "NUM_JOINTS"), ("h_dc_du", "NUM_JOINTS*2*NUM_JOINTS"), ("h_df_du", "NUM_JOINTS*2*NUM_JOINTS")]
         unused = ["d_M", "d_eePos", "d_deePos", "d_d2eePos", "d_idsva_so", "d_df2", "h_M", "h_eePos", "h_deePos", "h_d2eePos", "h_idsva_so", "h_df2"]
+        if self.gen_idsva_so_available():
+            dev.append(("d_idsva_so", "4*NUM_JOINTS*NUM_JOINTS*NUM_JOINTS"))
+            host.append(("h_idsva_so", "4*NUM_JOINTS*NUM_JOINTS*NUM_JOINTS"))
+            unused = [u for u in unused if u not in ("d_idsva_so", "h_idsva_so")]
         code = ["gridData<T> *hd_data = (gridData<T> *)malloc(sizeof(gridData<T>));",
                 "// device buffers of the dynamics algorithms"]
         code += ["gpuErrchk(hipMalloc((void**)&hd_data->" + nm + ", " + sz + "*NUM_TIMESTEPS*sizeof(T)));" for nm, sz in dev]
@@ -228,6 +234,7 @@ class GRiDCodeGenerator:
                                  "gpuErrchk(hipFree(hd_data->d_q_qd_u)); gpuErrchk(hipFree(hd_data->d_q_qd)); gpuErrchk(hipFree(hd_data->d_q));",
                                  "gpuErrchk(hipFree(hd_data->d_c)); gpuErrchk(hipFree(hd_data->d_Minv)); gpuErrchk(hipFree(hd_data->d_qdd));",
                                  "gpuErrchk(hipFree(hd_data->d_dc_du)); gpuErrchk(hipFree(hd_data->d_df_du));",
+                                 "if (hd_data->d_idsva_so) {gpuErrchk(hipFree(hd_data->d_idsva_so));} if (hd_data->h_idsva_so) {gpuErrchk(hipHostFree(hd_data->h_idsva_so));}",
                                  "gpuErrchk(hipHostFree(hd_data->h_q_qd_u)); gpuErrchk(hipHostFree(hd_data->h_q_qd)); gpuErrchk(hipHostFree(hd_data->h_q));",
                                  "gpuErrchk(hipHostFree(hd_data->h_c)); gpuErrchk(hipHostFree(hd_data->h_Minv)); gpuErrchk(hipHostFree(hd_data->h_qdd));",
                                  "gpuErrchk(hipHostFree(hd_data->h_dc_du)); gpuErrchk(hipHostFree(hd_data->h_df_du));",
@@ -307,6 +314,7 @@ class GRiDCodeGenerator:
         if self.tip_frame:
             self.gen_tip_frame_gradient(use_thread_group)
         self.gen_forward_dynamics_gradient(use_thread_group)
+        self.gen_idsva_so(use_thread_group)
         self.gen_init_close_grid()
         self.gen_add_end_control_flow()
         with open(self.file_namespace + ".cuh", "w") as f:

@@ -197,6 +197,30 @@ int grid_aba_device(grid_handle *h, const float *d_q_qd_tau, int stride_q_qd, in
     return 0;
 }
 
+int grid_idsva_so_device(grid_handle *h, const float *d_q_qd_u, int stride_q_qd_u, const float *d_qdd, int num_timesteps, float gravity,
+                         float *d_idsva_so, void *stream) {
+    int rc = check_args(h, num_timesteps);
+    if (rc) return rc;
+#if GRID_HAS_IDSVA_SO
+    if (num_timesteps == 0) return 0;
+    dim3 grid, block;
+    launch_dims(h, num_timesteps, &grid, &block);
+    if (d_qdd) {
+        hipLaunchKernelGGL((grid::idsva_so_kernel<float>), grid, block, lds_bytes(h), (hipStream_t)stream,
+                           d_idsva_so, d_q_qd_u, stride_q_qd_u, d_qdd, h->d_robotModel, gravity, num_timesteps);
+    } else {
+        hipLaunchKernelGGL((grid::idsva_so_kernel<float>), grid, block, lds_bytes(h), (hipStream_t)stream,
+                           d_idsva_so, d_q_qd_u, stride_q_qd_u, h->d_robotModel, gravity, num_timesteps);
+    }
+    GRID_TRY(hipGetLastError());
+    return 0;
+#else
+    (void)d_q_qd_u; (void)stride_q_qd_u; (void)d_qdd; (void)gravity; (void)d_idsva_so; (void)stream;
+    snprintf(g_err, sizeof(g_err), "idsva_so is emitted for serial revolute chains only; this library's robot is not one");
+    return (int)hipErrorNotSupported;
+#endif
+}
+
 int grid_inverse_dynamics_gradient_device(grid_handle *h, const float *d_q_qd, int stride_q_qd, const float *d_qdd, int num_timesteps, float gravity,
                                           float *d_dc_du, void *stream) {
     int rc = check_args(h, num_timesteps);

@@ -66,6 +66,10 @@ int grid_direct_minv_device(grid_handle *h, const float *d_q, int stride_q, int 
 int grid_forward_dynamics_device(grid_handle *h, const float *d_q_qd_u, int stride_q_qd_u, int num_timesteps, float gravity, float *d_qdd, void *stream);
 /* replaces aba_kernel<T> (reference algorithms/_aba.py:482-537): O(n) articulated-body forward dynamics, same result as grid_forward_dynamics_device */
 int grid_aba_device(grid_handle *h, const float *d_q_qd_tau, int stride_q_qd, int num_timesteps, float gravity, float *d_qdd, void *stream);
+/* replaces idsva_so_kernel<T> (reference algorithms/_idsva_so.py:958-1028): second-order derivatives of inverse dynamics, 4 n^3 values per solve
+ * [d2tau_dq2 | d2tau_dqd2 | d2tau_dvdq | dM_dq]; d_qdd may be NULL (qdd = 0).  Serial revolute chains only: other robots return hipErrorNotSupported */
+int grid_idsva_so_device(grid_handle *h, const float *d_q_qd_u, int stride_q_qd_u, const float *d_qdd, int num_timesteps, float gravity,
+                         float *d_idsva_so, void *stream);
 /* replaces inverse_dynamics_gradient_kernel<T> (reference algorithms/_inverse_dynamics_gradient.py:817-888); d_qdd may be NULL */
 int grid_inverse_dynamics_gradient_device(grid_handle *h, const float *d_q_qd, int stride_q_qd, const float *d_qdd, int num_timesteps, float gravity,
                                           float *d_dc_du, void *stream);

@@ -32,7 +32,7 @@ inline thread_local dim3 threadIdx, blockIdx, blockDim, gridDim;
 
 typedef int hipError_t;
 typedef void *hipStream_t;
-enum { hipSuccess = 0, hipErrorInvalidValue = 1, hipErrorInvalidConfiguration = 9 };
+enum { hipSuccess = 0, hipErrorInvalidValue = 1, hipErrorInvalidConfiguration = 9, hipErrorNotSupported = 801 };
 enum hipMemcpyKind { hipMemcpyHostToDevice, hipMemcpyDeviceToHost, hipMemcpyDeviceToDevice };
 enum { hipStreamNonBlocking = 1, hipHostMallocDefault = 0 };
 

@@ -182,3 +182,38 @@ def test_emulated_error_behaviour(libs):
         lib.forward_dynamics_gradient_device(np.zeros((4, 21), np.float32), -1, np.zeros((4, 98), np.float32))  # negative batch
     out = lib.forward_dynamics_gradient_host(np.zeros((1, 21), np.float32))  # still usable afterwards
     assert np.isfinite(out).all()
+
+
+@pytest.mark.parametrize("name", ["iiwa14", "arm6"])
+def test_emulated_idsva_so(name, libs, golden):
+    """second-order derivatives of inverse dynamics, against the NumPy restatement of the reference's emitter
+    (oracle/idsva_so_oracle.py; parity unpinned - the reference holds no vectors for it, see that module)."""
+    from gridcodegenerator_amd.robot import DuckRobot
+    from oracle.idsva_so_oracle import idsva_so
+
+    g = golden(name)
+    lib = libs(name)
+    n = lib.n
+    N = 3
+    lib.set_launch_dims(0, 64)
+    x = np.ascontiguousarray(np.hstack([g["q"], g["qd"], g["u"]]).astype(np.float32)[:N])
+    qdd = np.ascontiguousarray(g["qdd"].astype(np.float32)[:N])
+    model = DuckRobot(RobotModel.from_fixture(name))
+    for use_qdd in (True, False):
+        out = np.full((N, 4 * n ** 3), np.nan, np.float32)
+        lib.idsva_so_device(x, qdd if use_qdd else None, N, out)
+        assert np.isfinite(out).all()  # every entry is written
+        for k in range(N):
+            ref = idsva_so(model, x[k, :n].astype(np.float64), x[k, n:2 * n].astype(np.float64), qdd[k].astype(np.float64) if use_qdd else np.zeros(n))
+            got = out[k].reshape(4, n, n, n)
+            for t in range(4):
+                assert np.abs(got[t] - ref[t]).max() <= TOL * max(np.abs(ref[t]).max(), 1e-3), (k, t)
+    lib.set_launch_dims(0, 0)
+
+
+def test_emulated_idsva_so_is_refused_for_trees(libs):
+    from gridcodegenerator_amd.runtime import GridError
+
+    lib = libs("hyq")
+    with pytest.raises(GridError):
+        lib.idsva_so_device(np.zeros((1, 36), np.float32), None, 1, np.zeros((1, 4 * 12 ** 3), np.float32))

@@ -281,3 +281,48 @@ def test_non_default_generation_variants_on_gpu(env, torch_cuda, golden, tmp_pat
     ref2, _ = Oracle(RobotModel.from_fixture("iiwa14")).fd_grad_batch(xs.astype(np.float64))
     assert per_solve_err(run_fd_grad(torch_cuda, lib, xs), ref2) <= TOL
     lib.close()
+
+
+@pytest.mark.parametrize("name", ["iiwa14", "arm6", "chain12"])
+def test_idsva_so_matches_the_restated_reference_algorithm(name, torch_cuda, libs, golden):
+    """SURVEY.md section 8(f) rank 3 (serial revolute chains): second-order inverse-dynamics derivatives on the GPU vs the NumPy restatement of the
+    reference's emitter (oracle/idsva_so_oracle.py - parity unpinned, anchored on finite differences of the pinned first-order oracle)."""
+    from gridcodegenerator_amd.robot import DuckRobot
+    from oracle.idsva_so_oracle import idsva_so
+
+    torch = torch_cuda
+    g = golden(name)
+    lib = libs(name)
+    n = lib.n
+    N = g["q"].shape[0]
+    st = torch.cuda.current_stream().cuda_stream
+    xh = np.hstack([g["q"], g["qd"], g["u"]]).astype(np.float32)
+    qh = g["qdd"].astype(np.float32)
+    x, qdd = torch.from_numpy(xh).cuda(), torch.from_numpy(qh).cuda()
+    model = DuckRobot(RobotModel.from_fixture(name))
+    for use_qdd in (True, False):
+        out = torch.full((N, 4 * n ** 3), float("nan"), dtype=torch.float32, device="cuda")
+        lib.idsva_so_device(x, qdd if use_qdd else None, N, out, stream=st)
+        torch.cuda.synchronize()
+        got = out.cpu().numpy()
+        assert np.isfinite(got).all()  # every entry is written exactly once
+        for k in range(min(N, 4)):
+            ref = idsva_so(model, xh[k, :n].astype(np.float64), xh[k, n:2 * n].astype(np.float64), qh[k].astype(np.float64) if use_qdd else np.zeros(n))
+            for t in range(4):
+                assert np.abs(got[k].reshape(4, n, n, n)[t] - ref[t]).max() <= TOL * max(np.abs(ref[t]).max(), 1e-3), (k, t)
+    # ragged launch: more lane groups than solves, several trips per block
+    lib.set_launch_dims(3, 64)
+    out2 = torch.full((N, 4 * n ** 3), float("nan"), dtype=torch.float32, device="cuda")
+    lib.idsva_so_device(x, None, N, out2, stream=st)
+    torch.cuda.synchronize()
+    lib.set_launch_dims(0, 0)
+    assert np.array_equal(out2.cpu().numpy(), got)
+
+
+def test_idsva_so_is_refused_for_branched_robots(torch_cuda, libs):
+    from gridcodegenerator_amd.runtime import GridError
+
+    torch = torch_cuda
+    lib = libs("hyq")
+    with pytest.raises(GridError):
+        lib.idsva_so_device(torch.zeros((1, 36), device="cuda"), None, 1, torch.zeros((1, 4 * 12 ** 3), device="cuda"))
