@@ -36,6 +36,7 @@ class GRiDCodeGenerator:
         gen_forward_dynamics_host, gen_forward_dynamics, \
         gen_aba_inner_temp_mem_size, gen_aba_inner_function_call, gen_aba_inner, gen_aba_device, gen_aba_kernel, gen_aba_host, gen_aba, \
         gen_idsva_so_available, gen_idsva_so_inner_temp_mem_size, gen_idsva_so_inner_function_call, gen_idsva_so_inner, gen_idsva_so_device, gen_idsva_so_kernel, gen_idsva_so_host, gen_idsva_so, \
+        gen_fdsva_so_inner_temp_mem_size, gen_fdsva_so_stage_size, gen_fdsva_so_inner, gen_fdsva_so_device, gen_fdsva_so_kernel, gen_fdsva_so_host, gen_fdsva_so, \
         gen_inverse_dynamics_gradient_inner_temp_mem_size, gen_inverse_dynamics_gradient_kernel_max_temp_mem_size, \
         gen_inverse_dynamics_gradient_inner_function_call, gen_inverse_dynamics_gradient_inner, gen_dc_du_to_lds, gen_gradient_slots, gen_gradient_outputs_decl, \
         gen_inverse_dynamics_gradient_device, gen_inverse_dynamics_gradient_kernel, gen_inverse_dynamics_gradient_host, gen_inverse_dynamics_gradient, \
@@ -165,6 +166,11 @@ class GRiDCodeGenerator:
                                  "const int FD_DU_MAX_SHARED_MEM_COUNT = " + str(count) + ";",
                                  "// (reference bookkeeping) derivative columns that are structurally non-zero: dv/da " + str(dva_cols) + ", df " + str(df_cols)])
         self.gen_add_code_line("#define GRID_HAS_IDSVA_SO %d // the second-order inverse-dynamics derivatives are emitted for serial revolute chains" % (1 if self.gen_idsva_so_available() else 0))
+        if self.gen_idsva_so_available():
+            st_ = self.gen_fdsva_so_stage_size()
+            self.gen_add_code_lines(["const int FDSVA_SO_SUGGESTED_THREADS = 64; // fdsva_so keeps the 4 n^3 idsva_so tensors of every solve in LDS: fewer solves per block",
+                                     "const int FDSVA_SO_STAGE_PER_SOLVE = " + str(st_) + "; // df/du (2 n^2, padded) + idsva_so (4 n^3), behind the block's slices",
+                                     "const int FDSVA_SO_DYNAMIC_SHARED_MEM_COUNT = (FDSVA_SO_SUGGESTED_THREADS/GRID_LANES_PER_SOLVE)*(GRID_LDS_PER_SOLVE + FDSVA_SO_STAGE_PER_SOLVE);"])
         self.gen_add_code_line("// Define custom structs")
         self.gen_add_code_lines(["template <typename T>", "struct robotModel {", "    T *d_XImats;", "    int *d_topology_helpers;", "};"])
         self.gen_add_code_lines(["template <typename T>", "struct gridData {",
@@ -183,9 +189,9 @@ class GRiDCodeGenerator:
                 ("h_Minv", "NUM_JOINTS*NUM_JOINTS"), ("h_qdd", "NUM_JOINTS"), ("h_dc_du", "NUM_JOINTS*2*NUM_JOINTS"), ("h_df_du", "NUM_JOINTS*2*NUM_JOINTS")]
         unused = ["d_M", "d_eePos", "d_deePos", "d_d2eePos", "d_idsva_so", "d_df2", "h_M", "h_eePos", "h_deePos", "h_d2eePos", "h_idsva_so", "h_df2"]
         if self.gen_idsva_so_available():
-            dev.append(("d_idsva_so", "4*NUM_JOINTS*NUM_JOINTS*NUM_JOINTS"))
-            host.append(("h_idsva_so", "4*NUM_JOINTS*NUM_JOINTS*NUM_JOINTS"))
-            unused = [u for u in unused if u not in ("d_idsva_so", "h_idsva_so")]
+            dev += [("d_idsva_so", "4*NUM_JOINTS*NUM_JOINTS*NUM_JOINTS"), ("d_df2", "4*NUM_JOINTS*NUM_JOINTS*NUM_JOINTS")]
+            host += [("h_idsva_so", "4*NUM_JOINTS*NUM_JOINTS*NUM_JOINTS"), ("h_df2", "4*NUM_JOINTS*NUM_JOINTS*NUM_JOINTS")]
+            unused = [u for u in unused if u not in ("d_idsva_so", "h_idsva_so", "d_df2", "h_df2")]
         code = ["gridData<T> *hd_data = (gridData<T> *)malloc(sizeof(gridData<T>));",
                 "// device buffers of the dynamics algorithms"]
         code += ["gpuErrchk(hipMalloc((void**)&hd_data->" + nm + ", " + sz + "*NUM_TIMESTEPS*sizeof(T)));" for nm, sz in dev]
@@ -235,6 +241,7 @@ class GRiDCodeGenerator:
                                  "gpuErrchk(hipFree(hd_data->d_c)); gpuErrchk(hipFree(hd_data->d_Minv)); gpuErrchk(hipFree(hd_data->d_qdd));",
                                  "gpuErrchk(hipFree(hd_data->d_dc_du)); gpuErrchk(hipFree(hd_data->d_df_du));",
                                  "if (hd_data->d_idsva_so) {gpuErrchk(hipFree(hd_data->d_idsva_so));} if (hd_data->h_idsva_so) {gpuErrchk(hipHostFree(hd_data->h_idsva_so));}",
+                                 "if (hd_data->d_df2) {gpuErrchk(hipFree(hd_data->d_df2));} if (hd_data->h_df2) {gpuErrchk(hipHostFree(hd_data->h_df2));}",
                                  "gpuErrchk(hipHostFree(hd_data->h_q_qd_u)); gpuErrchk(hipHostFree(hd_data->h_q_qd)); gpuErrchk(hipHostFree(hd_data->h_q));",
                                  "gpuErrchk(hipHostFree(hd_data->h_c)); gpuErrchk(hipHostFree(hd_data->h_Minv)); gpuErrchk(hipHostFree(hd_data->h_qdd));",
                                  "gpuErrchk(hipHostFree(hd_data->h_dc_du)); gpuErrchk(hipHostFree(hd_data->h_df_du));",
@@ -315,6 +322,7 @@ class GRiDCodeGenerator:
             self.gen_tip_frame_gradient(use_thread_group)
         self.gen_forward_dynamics_gradient(use_thread_group)
         self.gen_idsva_so(use_thread_group)
+        self.gen_fdsva_so(use_thread_group)
         self.gen_init_close_grid()
         self.gen_add_end_control_flow()
         with open(self.file_namespace + ".cuh", "w") as f:

@@ -1,0 +1,193 @@
+"""Second-order derivatives of forward dynamics (FDSVA-SO), emitter for the HIP/CDNA4 backend - serial revolute chains.
+
+Mirrors the role of the reference's algorithms/_fdsva_so.py (gen_fdsva_so_inner :3-85, device :121-157, kernel :159-230, host :232-300):
+df2 = [d2a_dqdq | d2a_dvdv | d2a_dvdq | d2a_dtdq], four n x n x n tensors (flat index i*n*n + j*n + k) with
+    d2a_dqdq[i][j][k] = d2 qdd_i / dq_j dq_k,   d2a_dvdv[i][j][k] = d2 qdd_i / dqd_j dqd_k,
+    d2a_dvdq[i][j][k] = d2 qdd_i / dq_j dqd_k,  d2a_dtdq[i][j][k] = d Minv_ik / dq_j.
+The device function composes what the reference composes (:147-156): forward dynamics (qdd), its gradient (df/du), M^-1, idsva_so at that
+qdd, then the contraction of :52-81:
+    inner_dq[L][k][j]    = sum_P dM[L][j][P] dfdq[P][k] + sum_P dM[L][k][P] dfdq[P][j] + d2tau_dqdq[L][k][j]
+    inner_cross[L][k][j] = sum_P dM[L][k][P] dfdqd[P][j] + d2tau_dvdq[L][k][j]
+    inner_tau[L][k][j]   = sum_P dM[L][k][P] Minv[j][P]
+    out_x[i][k][j]       = -sum_L Minv[L][i] inner_x[L][k][j]          (x = dq, cross, tau; d2tau_dvdv itself for d2a_dvdv)
+Lane j owns the output entries (., k, j): it keeps column j of df/dq, df/dqd and row j of M^-1 in registers, walks k and L, and stores
+runs that are contiguous along j.  The idsva_so tensors of the solve stay in LDS (4 n^3 values), so a block carries fewer solves than the
+first-order kernels (FDSVA_SO_SUGGESTED_THREADS).
+
+Parity: PARITY UNPINNED (the reference ships no oracle or vectors); oracle/fdsva_so_oracle.py restates the reference's contraction and is
+anchored on finite differences of the pinned first-order forward-dynamics-gradient oracle.
+Scope this round: single serial chains of revolute joints, like idsva_so.
+"""
+
+
+def gen_fdsva_so_inner_temp_mem_size(self):
+    return 0
+
+
+def gen_fdsva_so_stage_size(self):
+    """Per-solve staging behind the block's slices: df/du (2 n^2, padded) then the idsva_so tensors (4 n^3)."""
+    n = self.model.n
+    return (2 * n * n + 3) // 4 * 4 + 4 * n * n * n
+
+
+def gen_fdsva_so_inner(self, use_thread_group=False):
+    n = self.model.n
+    n2, n3 = n * n, n * n * n
+    ld = self.minv_ld
+    self.gen_add_func_doc("Second Order of Forward Dynamics with Spatial Vector Algebra: the contraction of the idsva_so tensors with M^-1 and df/du",
+                          ["lane j produces the entries (., k, j) of the four output tensors and stores each exactly once; all lanes of the lane group must call it"],
+                          ["df2 is the output record of this solve: 4*NUM_JOINTS^3 values [d2a_dqdq | d2a_dvdv | d2a_dvdq | d2a_dtdq] (global or LDS memory)",
+                           "s_idsva_so are the second derivative tensors of inverse dynamics at qdd = FD(q, qd, u), in LDS",
+                           "s_Minv is the dense symmetric inverse mass matrix in LDS (leading dimension GRID_MINV_LD)",
+                           "s_df_du is the gradient of the forward dynamics in LDS ([col*n + row], col in [0, 2n))",
+                           "lane is the caller's lane index inside the solve's lane group", "active is false for lane groups without a solve"], None)
+    self.gen_add_code_line("template <typename T>")
+    self.gen_add_code_line("__device__ __forceinline__")
+    self.gen_add_code_line("void fdsva_so_inner(T *df2, const T *s_idsva_so, const T *s_Minv, const T *s_df_du, const int lane, const bool active) {", True)
+    lines = """
+const T *tqq = s_idsva_so, *tvv = s_idsva_so + @N3@, *tvq = s_idsva_so + 2*@N3@, *dM = s_idsva_so + 3*@N3@;
+const int j = (lane < @N@) ? lane : 0;
+const bool own = active && (lane < @N@);
+T fq_j[@N@], fv_j[@N@], mi_j[@N@]; // column j of df/dq and of df/dqd, row j of M^-1
+#pragma unroll
+for (int p = 0; p < @N@; p++) { fq_j[p] = s_df_du[j*@N@ + p]; fv_j[p] = s_df_du[(@N@ + j)*@N@ + p]; mi_j[p] = s_Minv[j*@LD@ + p]; }
+#pragma unroll 1
+for (int k = 0; k < @N@; k++) {
+    T fq_k[@N@];
+    #pragma unroll
+    for (int p = 0; p < @N@; p++) { fq_k[p] = s_df_du[k*@N@ + p]; }
+    T rq[@N@], rc[@N@], rv[@N@], rt[@N@]; // inner_dq, inner_cross, d2tau_dvdv, inner_tau at (L, k, j), L = 0..n-1
+    #pragma unroll
+    for (int L = 0; L < @N@; L++) {
+        const T *dMk = &dM[(L*@N@ + k)*@N@], *dMj = &dM[(L*@N@ + j)*@N@];
+        T aq = tqq[(L*@N@ + k)*@N@ + j], ac = tvq[(L*@N@ + k)*@N@ + j], at = static_cast<T>(0);
+        #pragma unroll
+        for (int p = 0; p < @N@; p++) { const T mk = dMk[p]; aq += dMj[p]*fq_k[p] + mk*fq_j[p]; ac += mk*fv_j[p]; at += mk*mi_j[p]; }
+        rq[L] = aq; rc[L] = ac; rt[L] = at; rv[L] = tvv[(L*@N@ + k)*@N@ + j];
+    }
+    #pragma unroll
+    for (int i = 0; i < @N@; i++) {
+        T oq = static_cast<T>(0), oc = static_cast<T>(0), ov = static_cast<T>(0), ot = static_cast<T>(0);
+        #pragma unroll
+        for (int L = 0; L < @N@; L++) { const T mi = s_Minv[L*@LD@ + i]; oq += mi*rq[L]; oc += mi*rc[L]; ov += mi*rv[L]; ot += mi*rt[L]; }
+        if (own) {
+            const int e = (i*@N@ + k)*@N@ + j;
+            df2[e] = -oq; df2[@N3@ + e] = -ov; df2[2*@N3@ + e] = -oc; df2[3*@N3@ + e] = -ot;
+        }
+    }
+}
+""".replace("@N3@", str(n3)).replace("@N@", str(n)).replace("@LD@", str(ld))
+    for line in lines.strip("\n").split("\n"):
+        self.gen_add_code_line(line)
+    self.gen_add_end_function()
+
+
+def gen_fdsva_so_device(self, use_thread_group=False):
+    n = self.model.n
+    self.gen_add_func_doc("Second Order of Forward Dynamics with Spatial Vector Algebra (lane-group cooperative): forward dynamics, its gradient, M^-1, idsva_so at the solution, contraction",
+                          ["all lanes of the solve's lane group must call it; s_df_du holds the first-order gradient on return (reference algorithms/_fdsva_so.py:147-156)"],
+                          ["df2 is the output record of this solve: 4*NUM_JOINTS^3 values (global or LDS memory)",
+                           "s_df_du is a pointer to LDS for the derivative of forward dynamics WRT q,qd of size 2*NUM_JOINTS*NUM_JOINTS = " + str(2 * n * n),
+                           "s_idsva_so is a pointer to LDS for the 4*NUM_JOINTS^3 second derivative tensors of inverse dynamics",
+                           "s_q is the vector of joint positions", "s_qd is the vector of joint velocities", "s_u is the vector of joint control inputs",
+                           "s_work is this solve's LDS workspace of GRID_LDS_PER_SOLVE elements",
+                           "d_robotModel is the pointer to the initialized model specific helpers on the GPU (XImats, topology_helpers, etc.)",
+                           "gravity is the gravity constant", "lane is the caller's lane index inside the solve's lane group", "active is false for lane groups without a solve"], None)
+    self.gen_add_code_line("template <typename T>")
+    self.gen_add_code_line("__device__ __forceinline__")
+    self.gen_add_code_line("void fdsva_so_device(T *df2, T *s_df_du, T *s_idsva_so, const T *s_q, const T *s_qd, const T *s_u, T *s_work, const robotModel<T> *d_robotModel, const T gravity, const int lane, const bool active) {", True)
+    self.gen_add_code_line("T *s_qdd = &s_work[GRID_OFF_QDD]; T *s_Minv = &s_work[GRID_OFF_MINV];")
+    self.gen_add_code_line("forward_dynamics_device<T>(s_qdd, s_q, s_qd, s_u, s_work, d_robotModel, gravity, lane);")
+    self.gen_add_code_line("forward_dynamics_gradient_device<T>(s_df_du, s_q, s_qd, s_u, s_work, d_robotModel, gravity, lane); // (uses the M^-1 slot as scratch: M^-1 comes after it)")
+    self.gen_add_code_line("direct_minv_device<T>(s_Minv, s_q, s_work, d_robotModel, lane);")
+    self.gen_add_code_line("idsva_so_device<T>(s_idsva_so, s_q, s_qd, s_qdd, s_work, d_robotModel, gravity, lane, true);")
+    self.gen_add_sync(use_thread_group)
+    self.gen_add_code_line("fdsva_so_inner<T>(df2, s_idsva_so, s_Minv, s_df_du, lane, active);")
+    self.gen_add_end_function()
+
+
+def gen_fdsva_so_kernel(self, use_thread_group=False, single_call_timing=False):
+    n = self.model.n
+    n3 = n * n * n
+    stage = self.gen_fdsva_so_stage_size()
+    func_params = ["d_df2 is the output: 4*NUM_JOINTS^3 values per solve, [d2a_dqdq | d2a_dvdv | d2a_dvdq | d2a_dtdq]",
+                   "d_q_qd_u is the vector of joint positions, velocities, and input torques", "stride_q_qd_u is the stride between each q, qd, u",
+                   "d_robotModel is the pointer to the initialized model specific helpers on the GPU (XImats, topology_helpers, etc.)",
+                   "gravity is the gravity constant",
+                   "num_timesteps is the length of the trajectory points we need to compute over (or overloaded as test_iters for timing)"]
+    func_def = "void fdsva_so_kernel(T *d_df2, const T *d_q_qd_u, const int stride_q_qd_u, const robotModel<T> *d_robotModel, const T gravity, const int NUM_TIMESTEPS) {"
+    if single_call_timing:
+        func_def = func_def.replace("kernel(", "kernel_single_timing(")
+    self.gen_add_func_doc("Second Order of Forward Dynamics with Spatial Vector Algebra",
+                          ["launch with FDSVA_SO_SUGGESTED_THREADS threads and FDSVA_SO_DYNAMIC_SHARED_MEM_COUNT*sizeof(T) bytes of dynamic LDS: every solve keeps its 4 n^3 idsva_so tensors in LDS"],
+                          func_params, None)
+    self.gen_add_code_line("template <typename T>")
+    self.gen_add_code_line("__global__ GRID_LAUNCH_BOUNDS")
+    self.gen_add_code_line(func_def, True)
+    self.gen_kernel_prologue("GRID_LDS_PER_SOLVE")
+    self.gen_add_code_lines(["T *s_q_qd_u = &s_mem[GRID_OFF_IN]; T *s_q = s_q_qd_u; T *s_qd = &s_q_qd_u[%d]; T *s_u = &s_q_qd_u[%d];" % (n, 2 * n),
+                             "T *s_df_du = &s_out_all[grp*%d]; T *s_idsva_so = s_df_du + %d;" % (stage, stage - 4 * n3)])
+    if single_call_timing:
+        self.gen_add_code_line("const int k = 0; const int kc = 0; const bool valid = (blockIdx.x + blockIdx.y == 0) && (grp == 0); const int lane = lane_id;")
+        self.gen_add_code_line("if (!valid) {return;}")
+    else:
+        self.gen_add_parallel_loop("k", "NUM_TIMESTEPS", use_thread_group, block_level=True)
+    self.gen_kernel_load_inputs("q_qd_u", "stride_q_qd_u", 3 * n, use_thread_group)
+    if single_call_timing:
+        self.gen_add_code_line("for (int rep = 0; rep < NUM_TIMESTEPS; rep++){", True)
+    self.gen_add_code_line("// compute; the record of solve k goes straight to global memory")
+    self.gen_add_code_line("fdsva_so_device<T>(&d_df2[static_cast<size_t>(kc)*%d], s_df_du, s_idsva_so, s_q, s_qd, s_u, s_mem, d_robotModel, gravity, lane, valid);" % (4 * n3))
+    self.gen_add_sync(use_thread_group)
+    if single_call_timing:
+        self.gen_add_end_control_flow()
+    if not single_call_timing:
+        self.gen_add_end_control_flow()
+    self.gen_add_end_function()
+
+
+def gen_fdsva_so_host(self, mode=0):
+    single_call_timing = mode == 1
+    compute_only = mode == 2
+    func_params = ["hd_data is the packaged input and output pointers",
+                   "d_robotModel is the pointer to the initialized model specific helpers on the GPU (XImats, topology_helpers, etc.)",
+                   "gravity is the gravity constant,",
+                   "num_timesteps is the length of the trajectory points we need to compute over (or overloaded as test_iters for timing)",
+                   "streams are pointers to HIP streams for async memory transfers (if needed)"]
+    name = "fdsva_so" + ("_single_timing" if single_call_timing else "") + ("_compute_only" if compute_only else "")
+    self.gen_add_func_doc("Second Order of Forward Dynamics with Spatial Vector Algebra", ["thread_dimms must not exceed FDSVA_SO_SUGGESTED_THREADS threads"], func_params, None)
+    self.gen_add_code_line("template <typename T>")
+    self.gen_add_code_line("__host__")
+    self.gen_add_code_line("void " + name + "(gridData<T> *hd_data, const robotModel<T> *d_robotModel, const T gravity, const int num_timesteps,")
+    self.gen_add_code_line("                      const dim3 block_dimms, const dim3 thread_dimms" + ("" if compute_only else ", hipStream_t *streams") + ") {", True)
+    self.gen_add_code_line("int stride_q_qd_u = 3*NUM_JOINTS;")
+    cnt = "" if single_call_timing else "num_timesteps*"
+    if not compute_only:
+        self.gen_add_code_lines(["// start code with memory transfer",
+                                 "gpuErrchk(hipMemcpyAsync(hd_data->d_q_qd_u,hd_data->h_q_qd_u,stride_q_qd_u*" + cnt + "sizeof(T),hipMemcpyHostToDevice,streams[0]));",
+                                 "gpuErrchk(hipDeviceSynchronize());"])
+    kern = "fdsva_so_kernel" + ("_single_timing" if single_call_timing else "") + "<T>"
+    self.gen_add_code_line("// then call the kernel")
+    if single_call_timing:
+        self.gen_add_code_line("struct timespec start, end; clock_gettime(CLOCK_MONOTONIC,&start);")
+    self.gen_add_code_lines(["hipLaunchKernelGGL((" + kern + "),block_dimms,thread_dimms,FDSVA_SO_DYNAMIC_SHARED_MEM_COUNT*sizeof(T),0,hd_data->d_df2,hd_data->d_q_qd_u,stride_q_qd_u,d_robotModel,gravity,num_timesteps);",
+                             "gpuErrchk(hipGetLastError()); gpuErrchk(hipDeviceSynchronize());"])
+    if single_call_timing:
+        self.gen_add_code_line("clock_gettime(CLOCK_MONOTONIC,&end);")
+    if not compute_only:
+        self.gen_add_code_lines(["// finally transfer the result back",
+                                 "gpuErrchk(hipMemcpy(hd_data->h_df2,hd_data->d_df2,4*NUM_JOINTS*NUM_JOINTS*NUM_JOINTS*" + cnt + "sizeof(T),hipMemcpyDeviceToHost));",
+                                 "gpuErrchk(hipDeviceSynchronize());"])
+    if single_call_timing:
+        self.gen_add_code_line("printf(\"Single Call FDSVA_SO %fus\\n\",time_delta_us_timespec(start,end)/static_cast<double>(num_timesteps));")
+    self.gen_add_end_function()
+
+
+def gen_fdsva_so(self, use_thread_group=False):
+    if not self.gen_idsva_so_available():
+        return
+    self.gen_fdsva_so_inner(use_thread_group)
+    self.gen_fdsva_so_device(use_thread_group)
+    self.gen_fdsva_so_kernel(use_thread_group, True)
+    self.gen_fdsva_so_kernel(use_thread_group, False)
+    for mode in (0, 1, 2):
+        self.gen_fdsva_so_host(mode)

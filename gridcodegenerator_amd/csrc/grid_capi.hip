@@ -221,6 +221,28 @@ int grid_idsva_so_device(grid_handle *h, const float *d_q_qd_u, int stride_q_qd_
 #endif
 }
 
+int grid_fdsva_so_device(grid_handle *h, const float *d_q_qd_u, int stride_q_qd_u, int num_timesteps, float gravity, float *d_df2, void *stream) {
+    int rc = check_args(h, num_timesteps);
+    if (rc) return rc;
+#if GRID_HAS_IDSVA_SO
+    if (num_timesteps == 0) return 0;
+    int threads = h->threads > 0 ? h->threads : grid::FDSVA_SO_SUGGESTED_THREADS;
+    if (threads > grid::FDSVA_SO_SUGGESTED_THREADS) threads = grid::FDSVA_SO_SUGGESTED_THREADS;
+    int gpb = threads / grid::GRID_LANES_PER_SOLVE;
+    if (gpb < 1) { gpb = 1; threads = grid::GRID_LANES_PER_SOLVE; }
+    int blocks = h->blocks > 0 ? h->blocks : (num_timesteps + gpb - 1) / gpb;
+    const size_t lds = (size_t)gpb * (grid::GRID_LDS_PER_SOLVE + grid::FDSVA_SO_STAGE_PER_SOLVE) * sizeof(float);
+    hipLaunchKernelGGL((grid::fdsva_so_kernel<float>), dim3(blocks, 1, 1), dim3(threads, 1, 1), lds, (hipStream_t)stream,
+                       d_df2, d_q_qd_u, stride_q_qd_u, h->d_robotModel, gravity, num_timesteps);
+    GRID_TRY(hipGetLastError());
+    return 0;
+#else
+    (void)d_q_qd_u; (void)stride_q_qd_u; (void)gravity; (void)d_df2; (void)stream;
+    snprintf(g_err, sizeof(g_err), "fdsva_so is emitted for serial revolute chains only; this library's robot is not one");
+    return (int)hipErrorNotSupported;
+#endif
+}
+
 int grid_inverse_dynamics_gradient_device(grid_handle *h, const float *d_q_qd, int stride_q_qd, const float *d_qdd, int num_timesteps, float gravity,
                                           float *d_dc_du, void *stream) {
     int rc = check_args(h, num_timesteps);

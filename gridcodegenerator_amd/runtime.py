@@ -172,6 +172,10 @@ class GridLibrary:
         self._check(self.lib.grid_idsva_so_device(self.handle, _ptr(d_q_qd_u), ctypes.c_int(stride or 3 * self.n), _ptr(d_qdd), ctypes.c_int(N),
                                                   ctypes.c_float(gravity), _ptr(d_idsva_so), ctypes.c_void_p(stream)))
 
+    def fdsva_so_device(self, d_q_qd_u, N, d_df2, stride=None, gravity=9.81, stream=0):
+        self._check(self.lib.grid_fdsva_so_device(self.handle, _ptr(d_q_qd_u), ctypes.c_int(stride or 3 * self.n), ctypes.c_int(N),
+                                                  ctypes.c_float(gravity), _ptr(d_df2), ctypes.c_void_p(stream)))
+
     def inverse_dynamics_gradient_device(self, d_q_qd, d_qdd, N, d_dc_du, stride=None, gravity=9.81, stream=0):
         self._check(self.lib.grid_inverse_dynamics_gradient_device(self.handle, _ptr(d_q_qd), ctypes.c_int(stride or 3 * self.n), _ptr(d_qdd), ctypes.c_int(N),
                                                                    ctypes.c_float(gravity), _ptr(d_dc_du), ctypes.c_void_p(stream)))

@@ -70,6 +70,10 @@ int grid_aba_device(grid_handle *h, const float *d_q_qd_tau, int stride_q_qd, in
  * [d2tau_dq2 | d2tau_dqd2 | d2tau_dvdq | dM_dq]; d_qdd may be NULL (qdd = 0).  Serial revolute chains only: other robots return hipErrorNotSupported */
 int grid_idsva_so_device(grid_handle *h, const float *d_q_qd_u, int stride_q_qd_u, const float *d_qdd, int num_timesteps, float gravity,
                          float *d_idsva_so, void *stream);
+/* replaces fdsva_so_kernel<T> (reference algorithms/_fdsva_so.py:159-230): second-order derivatives of forward dynamics, 4 n^3 values per solve
+ * [d2a_dqdq | d2a_dvdv | d2a_dvdq | d2a_dtdq].  Serial revolute chains only (hipErrorNotSupported otherwise); launches with at most
+ * FDSVA_SO_SUGGESTED_THREADS threads per block whatever grid_set_launch_dims() says */
+int grid_fdsva_so_device(grid_handle *h, const float *d_q_qd_u, int stride_q_qd_u, int num_timesteps, float gravity, float *d_df2, void *stream);
 /* replaces inverse_dynamics_gradient_kernel<T> (reference algorithms/_inverse_dynamics_gradient.py:817-888); d_qdd may be NULL */
 int grid_inverse_dynamics_gradient_device(grid_handle *h, const float *d_q_qd, int stride_q_qd, const float *d_qdd, int num_timesteps, float gravity,
                                           float *d_dc_du, void *stream);

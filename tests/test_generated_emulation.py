@@ -217,3 +217,32 @@ def test_emulated_idsva_so_is_refused_for_trees(libs):
     lib = libs("hyq")
     with pytest.raises(GridError):
         lib.idsva_so_device(np.zeros((1, 36), np.float32), None, 1, np.zeros((1, 4 * 12 ** 3), np.float32))
+
+
+@pytest.mark.parametrize("name", ["iiwa14", "arm6"])
+def test_emulated_fdsva_so(name, libs, golden):
+    """Second half of SURVEY.md section 8(f) rank 3: second-order derivatives of forward dynamics, against the NumPy restatements of the reference's
+    idsva_so + fdsva_so emitters fed by the pinned first-order oracle (parity unpinned, see oracle/fdsva_so_oracle.py)."""
+    from gridcodegenerator_amd.robot import DuckRobot
+    from oracle.fdsva_so_oracle import fdsva_so
+    from oracle.idsva_so_oracle import idsva_so
+    from oracle.rbd_oracle import Oracle
+
+    g = golden(name)
+    lib = libs(name)
+    n = lib.n
+    N = 3
+    x = np.ascontiguousarray(np.hstack([g["q"], g["qd"], g["u"]]).astype(np.float32)[:N])
+    robot = RobotModel.from_fixture(name)
+    model, orc = DuckRobot(robot), Oracle(robot)
+    out = np.full((N, 4 * n ** 3), np.nan, np.float32)
+    lib.fdsva_so_device(x, N, out)
+    assert np.isfinite(out).all()
+    for k in range(N):
+        q, qd, u = (x[k, i * n:(i + 1) * n].astype(np.float64) for i in range(3))
+        df_du, qdd, Minv, _ = orc.fd_grad(q, qd, u, full=True)
+        so = np.concatenate([t.reshape(-1) for t in idsva_so(model, q, qd, qdd)])
+        ref = fdsva_so(so, Minv, df_du).reshape(4, n, n, n)
+        got = out[k].reshape(4, n, n, n)
+        for t in range(4):
+            assert np.abs(got[t] - ref[t]).max() <= TOL * max(np.abs(ref[t]).max(), 1e-3), (k, t)

@@ -326,3 +326,35 @@ def test_idsva_so_is_refused_for_branched_robots(torch_cuda, libs):
     lib = libs("hyq")
     with pytest.raises(GridError):
         lib.idsva_so_device(torch.zeros((1, 36), device="cuda"), None, 1, torch.zeros((1, 4 * 12 ** 3), device="cuda"))
+
+
+@pytest.mark.parametrize("name", ["iiwa14", "arm6", "chain12"])
+def test_fdsva_so_matches_the_restated_reference_algorithm(name, torch_cuda, libs, golden):
+    """Second half of SURVEY.md section 8(f) rank 3 (serial revolute chains): second-order forward-dynamics derivatives on the GPU vs the NumPy
+    restatements of the reference's idsva_so + fdsva_so emitters fed by the pinned first-order oracle (parity unpinned)."""
+    from gridcodegenerator_amd.robot import DuckRobot
+    from oracle.fdsva_so_oracle import fdsva_so
+    from oracle.idsva_so_oracle import idsva_so
+    from oracle.rbd_oracle import Oracle
+
+    torch = torch_cuda
+    g = golden(name)
+    lib = libs(name)
+    n = lib.n
+    N = g["q"].shape[0]
+    st = torch.cuda.current_stream().cuda_stream
+    xh = np.hstack([g["q"], g["qd"], g["u"]]).astype(np.float32)
+    out = torch.full((N, 4 * n ** 3), float("nan"), dtype=torch.float32, device="cuda")
+    lib.fdsva_so_device(torch.from_numpy(xh).cuda(), N, out, stream=st)
+    torch.cuda.synchronize()
+    got = out.cpu().numpy()
+    assert np.isfinite(got).all()
+    robot = RobotModel.from_fixture(name)
+    model, orc = DuckRobot(robot), Oracle(robot)
+    for k in range(min(N, 3)):
+        q, qd, u = (xh[k, i * n:(i + 1) * n].astype(np.float64) for i in range(3))
+        df_du, qdd, Minv, _ = orc.fd_grad(q, qd, u, full=True)
+        so = np.concatenate([t.reshape(-1) for t in idsva_so(model, q, qd, qdd)])
+        ref = fdsva_so(so, Minv, df_du).reshape(4, n, n, n)
+        for t in range(4):
+            assert np.abs(got[k].reshape(4, n, n, n)[t] - ref[t]).max() <= TOL * max(np.abs(ref[t]).max(), 1e-3), (k, t)

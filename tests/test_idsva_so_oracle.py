@@ -36,3 +36,31 @@ def test_second_order_oracle_matches_finite_differences_of_the_first_order_oracl
         ref = finite_difference_tensors(orc, n, q, qd, qdd)
         for a, b in zip(got, ref):
             assert np.abs(a - b).max() <= 1e-7 * max(np.abs(b).max(), 1.0)
+
+
+@pytest.mark.parametrize("name", ["iiwa14", "arm6", "hyq"])
+def test_fdsva_so_oracle_matches_finite_differences_of_the_first_order_oracle(name):
+    from oracle.fdsva_so_oracle import fdsva_so
+
+    rm = RobotModel.from_fixture(name)
+    m = DuckRobot(rm)
+    n = m.n
+    orc = Oracle(rm)
+    rng = np.random.default_rng(4)
+    q, qd, u = rng.uniform(-np.pi, np.pi, n), rng.uniform(-2, 2, n), rng.uniform(-10, 10, n)
+    df_du, qdd, Minv, _ = orc.fd_grad(q, qd, u, full=True)
+    so = np.concatenate([t.reshape(-1) for t in idsva_so(m, q, qd, qdd)])
+    got = fdsva_so(so, Minv, df_du).reshape(4, n, n, n)
+    h = 1e-5
+    ref = np.zeros((4, n, n, n))
+    for k in range(n):
+        e = np.zeros(n)
+        e[k] = h
+        d = (orc.fd_grad(q + e, qd, u) - orc.fd_grad(q - e, qd, u)) / (2 * h)       # d/dq_k of [dqdd/dq | dqdd/dqd]
+        ref[0][:, :, k] = d[:, :n]
+        ref[2][:, k, :] = d[:, n:]
+        ref[3][:, k, :] = (orc.minv(q + e) - orc.minv(q - e)) / (2 * h)
+        d = (orc.fd_grad(q, qd + e, u) - orc.fd_grad(q, qd - e, u)) / (2 * h)
+        ref[1][:, :, k] = d[:, n:]
+    for t in range(4):
+        assert np.abs(got[t] - ref[t]).max() <= 2e-6 * max(np.abs(ref[t]).max(), 1.0), t

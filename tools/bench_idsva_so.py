@@ -26,4 +26,13 @@ for N in batches:
     by = 4 * (3 * n + 4 * n ** 3)
     print(json.dumps({"robot": name, "kernel": "idsva_so (with qdd)", "batch": N, "us_per_launch": round(us, 2), "solves_per_s": round(N / us * 1e6),
                       "hbm_GBps_algorithmic": round(by * N / us / 1e3, 1), "hbm_frac_of_8TBps": round(by * N / us / 1e3 / 8000, 3)}))
+    d_out2 = torch.empty((N, 4 * n ** 3), dtype=torch.float32, device="cuda")
+    for _ in range(3): lib.fdsva_so_device(d_in, N, d_out2, stream=st)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(K): lib.fdsva_so_device(d_in, N, d_out2, stream=st)
+    e1.record(); torch.cuda.synchronize()
+    us = 1e3 * e0.elapsed_time(e1) / K
+    print(json.dumps({"robot": name, "kernel": "fdsva_so", "batch": N, "us_per_launch": round(us, 2), "solves_per_s": round(N / us * 1e6),
+                      "hbm_GBps_algorithmic": round(by * N / us / 1e3, 1), "hbm_frac_of_8TBps": round(by * N / us / 1e3 / 8000, 3)}))
     lib.close()
