@@ -35,7 +35,7 @@ class GRiDCodeGenerator:
         gen_forward_dynamics_inner_function_call, gen_forward_dynamics_inner, gen_forward_dynamics_device, gen_forward_dynamics_kernel, \
         gen_forward_dynamics_host, gen_forward_dynamics, \
         gen_aba_inner_temp_mem_size, gen_aba_inner_function_call, gen_aba_inner, gen_aba_device, gen_aba_kernel, gen_aba_host, gen_aba, \
-        gen_idsva_so_available, gen_idsva_so_inner_temp_mem_size, gen_idsva_so_inner_function_call, gen_idsva_so_inner, gen_idsva_so_device, gen_idsva_so_kernel, gen_idsva_so_host, gen_idsva_so, \
+        gen_idsva_so_available, gen_idsva_so_lds_layout, gen_idsva_so_inner_temp_mem_size, gen_idsva_so_inner_function_call, gen_idsva_so_inner, gen_idsva_so_device, gen_idsva_so_kernel, gen_idsva_so_host, gen_idsva_so, \
         gen_fdsva_so_inner_temp_mem_size, gen_fdsva_so_stage_size, gen_fdsva_so_inner, gen_fdsva_so_device, gen_fdsva_so_kernel, gen_fdsva_so_host, gen_fdsva_so, \
         gen_inverse_dynamics_gradient_inner_temp_mem_size, gen_inverse_dynamics_gradient_kernel_max_temp_mem_size, \
         gen_inverse_dynamics_gradient_inner_function_call, gen_inverse_dynamics_gradient_inner, gen_dc_du_to_lds, gen_gradient_slots, gen_gradient_outputs_decl, \
@@ -160,13 +160,19 @@ class GRiDCodeGenerator:
                                  "// the *_DYNAMIC_SHARED_MEM_COUNT constants below are that amount for SUGGESTED_THREADS"])
         for k in ("IN", "X", "U", "T", "MINV", "QDD", "F", "J"):
             self.gen_add_code_line("const int GRID_OFF_" + k + " = " + str(lds[k]) + ";")
-        for k in ("ID", "MINV", "FD", "ABA", "ID_DU", "FD_DU", "IDSVA_SO"):
+        for k in ("ID", "MINV", "FD", "ABA", "ID_DU", "FD_DU"):
             self.gen_add_code_line("const int " + k + "_DYNAMIC_SHARED_MEM_COUNT = " + str(count) + ";")
         self.gen_add_code_lines(["const int ID_DU_MAX_SHARED_MEM_COUNT = " + str(count) + ";",
                                  "const int FD_DU_MAX_SHARED_MEM_COUNT = " + str(count) + ";",
                                  "// (reference bookkeeping) derivative columns that are structurally non-zero: dv/da " + str(dva_cols) + ", df " + str(df_cols)])
         self.gen_add_code_line("#define GRID_HAS_IDSVA_SO %d // the second-order inverse-dynamics derivatives are emitted for serial revolute chains" % (1 if self.gen_idsva_so_available() else 0))
         if self.gen_idsva_so_available():
+            sl_, scr_, stg_, thr_ = self.gen_idsva_so_lds_layout()
+            self.gen_add_code_lines(["const int IDSVA_SO_SUGGESTED_THREADS = %d; // idsva_so stages the 4 n^3 record of every solve in LDS: fewer solves per block" % thr_,
+                                     "const int IDSVA_SO_LDS_PER_SOLVE = %d; // compact slice of the idsva_so kernels: q | qd | qdd | scratch" % sl_,
+                                     "const int IDSVA_SO_SCRATCH_PER_SOLVE = %d; // X(q) / per-joint records + a zero qdd vector" % scr_,
+                                     "const int IDSVA_SO_STAGE_PER_SOLVE = %d;" % stg_,
+                                     "const int IDSVA_SO_DYNAMIC_SHARED_MEM_COUNT = (IDSVA_SO_SUGGESTED_THREADS/GRID_LANES_PER_SOLVE)*(IDSVA_SO_LDS_PER_SOLVE + IDSVA_SO_STAGE_PER_SOLVE);"])
             st_ = self.gen_fdsva_so_stage_size()
             self.gen_add_code_lines(["const int FDSVA_SO_SUGGESTED_THREADS = 64; // fdsva_so keeps the 4 n^3 idsva_so tensors of every solve in LDS: fewer solves per block",
                                      "const int FDSVA_SO_STAGE_PER_SOLVE = " + str(st_) + "; // df/du (2 n^2, padded) + idsva_so (4 n^3), behind the block's slices",

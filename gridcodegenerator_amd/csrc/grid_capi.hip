@@ -203,13 +203,18 @@ int grid_idsva_so_device(grid_handle *h, const float *d_q_qd_u, int stride_q_qd_
     if (rc) return rc;
 #if GRID_HAS_IDSVA_SO
     if (num_timesteps == 0) return 0;
-    dim3 grid, block;
-    launch_dims(h, num_timesteps, &grid, &block);
+    int threads = h->threads > 0 ? h->threads : grid::IDSVA_SO_SUGGESTED_THREADS;
+    if (threads > grid::IDSVA_SO_SUGGESTED_THREADS) threads = grid::IDSVA_SO_SUGGESTED_THREADS;
+    int gpb = threads / grid::GRID_LANES_PER_SOLVE;
+    if (gpb < 1) { gpb = 1; threads = grid::GRID_LANES_PER_SOLVE; }
+    const int blocks = h->blocks > 0 ? h->blocks : (num_timesteps + gpb - 1) / gpb;
+    const size_t lds = (size_t)gpb * (grid::IDSVA_SO_LDS_PER_SOLVE + grid::IDSVA_SO_STAGE_PER_SOLVE) * sizeof(float);
+    const dim3 grid(blocks, 1, 1), block(threads, 1, 1);
     if (d_qdd) {
-        hipLaunchKernelGGL((grid::idsva_so_kernel<float>), grid, block, lds_bytes(h), (hipStream_t)stream,
+        hipLaunchKernelGGL((grid::idsva_so_kernel<float>), grid, block, lds, (hipStream_t)stream,
                            d_idsva_so, d_q_qd_u, stride_q_qd_u, d_qdd, h->d_robotModel, gravity, num_timesteps);
     } else {
-        hipLaunchKernelGGL((grid::idsva_so_kernel<float>), grid, block, lds_bytes(h), (hipStream_t)stream,
+        hipLaunchKernelGGL((grid::idsva_so_kernel<float>), grid, block, lds, (hipStream_t)stream,
                            d_idsva_so, d_q_qd_u, stride_q_qd_u, h->d_robotModel, gravity, num_timesteps);
     }
     GRID_TRY(hipGetLastError());

@@ -67,7 +67,8 @@ int grid_forward_dynamics_device(grid_handle *h, const float *d_q_qd_u, int stri
 /* replaces aba_kernel<T> (reference algorithms/_aba.py:482-537): O(n) articulated-body forward dynamics, same result as grid_forward_dynamics_device */
 int grid_aba_device(grid_handle *h, const float *d_q_qd_tau, int stride_q_qd, int num_timesteps, float gravity, float *d_qdd, void *stream);
 /* replaces idsva_so_kernel<T> (reference algorithms/_idsva_so.py:958-1028): second-order derivatives of inverse dynamics, 4 n^3 values per solve
- * [d2tau_dq2 | d2tau_dqd2 | d2tau_dvdq | dM_dq]; d_qdd may be NULL (qdd = 0).  Serial revolute chains only: other robots return hipErrorNotSupported */
+ * [d2tau_dq2 | d2tau_dqd2 | d2tau_dvdq | dM_dq]; d_qdd may be NULL (qdd = 0).  Serial revolute chains only: other robots return hipErrorNotSupported;
+ * launches with at most IDSVA_SO_SUGGESTED_THREADS threads per block whatever grid_set_launch_dims() says */
 int grid_idsva_so_device(grid_handle *h, const float *d_q_qd_u, int stride_q_qd_u, const float *d_qdd, int num_timesteps, float gravity,
                          float *d_idsva_so, void *stream);
 /* replaces fdsva_so_kernel<T> (reference algorithms/_fdsva_so.py:159-230): second-order derivatives of forward dynamics, 4 n^3 values per solve

@@ -9,7 +9,8 @@ name = sys.argv[1] if len(sys.argv) > 1 else "iiwa14"
 batches = [int(a) for a in sys.argv[2:]] or [1024, 16384, 65536]
 robot = RobotModel.from_fixture(name); n = robot.n
 for N in batches:
-    lib = load(name, max_timesteps=N)
+    import os
+    lib = load(name, max_timesteps=N, build_dir=os.environ.get("GRID_SWEEP_BUILD_DIR"))
     rng = np.random.default_rng(0)
     x = np.hstack([rng.uniform(-np.pi, np.pi, (N, n)), rng.uniform(-2, 2, (N, n)), rng.uniform(-10, 10, (N, n))]).astype(np.float32)
     d_in = torch.from_numpy(x).cuda(); d_qdd = torch.from_numpy(rng.uniform(-5, 5, (N, n)).astype(np.float32)).cuda()
