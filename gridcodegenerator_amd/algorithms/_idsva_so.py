@@ -66,7 +66,7 @@ def gen_idsva_so_inner(self, use_thread_group=False, use_qdd_input=False):
                            "lane is the caller's lane index inside the solve's lane group", "active is false for lane groups without a solve (they compute but do not store)"], None)
     self.gen_add_code_line("template <typename T>")
     self.gen_add_code_line("__device__ __forceinline__")
-    self.gen_add_code_line("void idsva_so_inner(T *so, const T *s_qd, const T *s_qdd, T *s_X, const robotModel<T> *d_robotModel, const T gravity, const int lane, const bool active) {", True)
+    self.gen_add_code_line("void idsva_so_inner(T *__restrict__ so, const T *__restrict__ s_qd, const T *__restrict__ s_qdd, T *__restrict__ s_X, const robotModel<T> *d_robotModel, const T gravity, const int lane, const bool active) {", True)
     _emit_link_constants_load(self)
     _emit_chain_decls(self)
     for i in range(self.tip_L - 1, -1, -1):
@@ -141,7 +141,7 @@ for (int m = 0; m < @N@; m++) {
         for (int r = 0; r < 6; r++) { d2P[r] = -u[r] - w[r]; }
         grid_fxv_peq(d2P, Pd, IyP); grid_fxv_peq(d2P, yP, ICPd); grid_bmul(t, BC, yP); grid_fxv_peq(d2P, S, t);
     }
-    #pragma unroll 1
+    #pragma unroll @UNROLL_L@
     for (int l = 0; l < @N@; l++) {
         T xS[6], xP[6];
         #pragma unroll
@@ -202,6 +202,7 @@ for (int m = 0; m < @N@; m++) {
 """.replace("@N@", str(n)).replace("@N3@", str(n3))
     import os
     # timing ablation only (GRID_DEBUG_STOP=30): everything is computed, (almost) nothing is stored
+    lines = lines.replace("@UNROLL_L@", os.environ.get("GRID_SO_UNROLL", str(n)))  # tuning knob: inner-loop unrolling of idsva_so (full: -7 % vs none on the 7-DoF arm)
     lines = lines.replace("@NOSTORE@", " && (gravity < static_cast<T>(-1e30))" if os.environ.get("GRID_DEBUG_STOP", "0") == "30" else "")
     for line in lines.strip("\n").split("\n"):
         self.gen_add_code_line(line)
