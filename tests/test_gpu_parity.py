@@ -229,7 +229,7 @@ def test_generated_host_api_float_and_double(torch_cuda, golden, tmp_path):
 @pytest.mark.parametrize("name", ["iiwa14", "arm6", "hyq"])
 def test_fd_grad_on_ill_conditioned_configurations(name, torch_cuda, libs):
     """Edge cases of the domain: joint angles that line up every other joint axis (the worst conditioned joint-space inertia a chain
-    has), a wide input range, and the worst state a 10^6-state random sweep found for the tip-frame path (tools/parity_sweep.py:
+    has), a wide input range, and the worst state a 10^6-state random sweep found for the tip-frame path (tests/tools/parity_sweep.py:
     4.5e-5 of max|df/du| near a shoulder + wrist alignment of the 7-DoF arm).  The acceptance bar is the same 1e-4."""
     from oracle.rbd_oracle import Oracle
 

@@ -1,7 +1,7 @@
 """BASELINE.json config 2 (iiwa-14 inverse_dynamics + inverse_dynamics_gradient, batch 1024) and the other stand-alone kernels of
 SURVEY.md section 8(f) rows 1-2, each checked against the CPU oracle on the same inputs and timed beside it.  Prints one JSON line per kernel."""
 import json, sys, time
-sys.path.insert(0, ".")
+sys.path.insert(0, ".")  # run from the repo root
 import numpy as np, torch
 from gridcodegenerator_amd import RobotModel
 from gridcodegenerator_amd.runtime import load

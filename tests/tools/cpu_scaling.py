@@ -1,5 +1,5 @@
 import sys, time, os
-sys.path.insert(0, ".")
+sys.path.insert(0, ".")  # run from the repo root
 import numpy as np
 import bench
 from gridcodegenerator_amd import RobotModel

@@ -2,7 +2,7 @@
 """Large randomized parity sweep of forward_dynamics_gradient on the GPU against the fp64 C oracle (test infrastructure, oracle/).
 usage: python tools/parity_sweep.py [robot ...]   prints one JSON line per (robot, input distribution)."""
 import json, sys
-sys.path.insert(0, ".")
+sys.path.insert(0, ".")  # run from the repo root
 import numpy as np, torch
 from gridcodegenerator_amd import RobotModel
 from gridcodegenerator_amd.runtime import load

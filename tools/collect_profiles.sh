@@ -8,5 +8,5 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -o run -- pytho
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -o run -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-parity > /dev/null 2> $O/pmc_fetch.err || exit 1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -o run -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-parity > /dev/null 2> $O/pmc_write.err || exit 1
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS --kernel-trace --output-format csv -d $O/pmc_sq -o run -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-parity > /dev/null 2> $O/pmc_sq.err || exit 1
-python3 tools/bench_components.py > $O/components.jsonl 2> /dev/null || exit 1
+python3 tests/tools/bench_components.py > $O/components.jsonl 2> /dev/null || exit 1
 echo done
