@@ -73,7 +73,7 @@ def gen_idsva_so_inner(self, use_thread_group=False, use_qdd_input=False):
         _chain_step(self, i)
     self.gen_add_sync(use_thread_group)  # every lane is done with s_X before the records overwrite it
     _emit_link_setup(self)
-    self.gen_add_code_line("const T qdd = s_qdd[lane];")
+    self.gen_add_code_line("const T qdd = (lane < %d) ? s_qdd[lane] : static_cast<T>(0);" % n)
     _emit_bias(self, True)
     lines = """
 T Pdd[6]; grid_mxm(Pdd, a, S); grid_mxm_peq(Pdd, v, Pd);

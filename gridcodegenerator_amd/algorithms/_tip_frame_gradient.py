@@ -270,7 +270,7 @@ def _emit_link_setup(self, kinematics=True):
     self.gen_add_code_line("//")
     self.gen_add_code_line("T mku[GRID_SCAN_STEPS], mkd[GRID_SCAN_STEPS]; grid_prefix_masks(mku, pos); grid_suffix_masks(mkd, pos);")
     if kinematics:
-        self.gen_add_code_line("const T qd = s_qd[lane]; // (lanes without a joint read a neighbouring finite value: their inertia is zero and nothing reads their prefix sums)")
+        self.gen_add_code_line("const T qd = (lane < %d) ? s_qd[lane] : static_cast<T>(0); // lanes without a joint must contribute exact zeros to the scans (0 * uninitialised LDS may be NaN)" % n)
     self.gen_add_code_line("T S[6];")
     if same_axis:
         a = m.S_index[0]
@@ -499,7 +499,7 @@ def gen_forward_dynamics_gradient_inner_tip(self, use_thread_group=False, use_qd
     if use_qdd_Minv_input:
         self.gen_add_sync(use_thread_group)  # every lane is done with s_X before the hand-off records overwrite it
         _emit_link_setup(self)
-        self.gen_add_code_line("const T qdd = s_qdd[lane];")
+        self.gen_add_code_line("const T qdd = (lane < %d) ? s_qdd[lane] : static_cast<T>(0);" % n)
         _emit_bias(self, True)
         _emit_assembly(self, s_G="s_X")
         self.gen_add_end_function()
@@ -698,7 +698,7 @@ def gen_inverse_dynamics_inner_tip(self, use_thread_group=False):
                        "s_qdd is the vector of joint accelerations in LDS, or nullptr for qdd = 0", "s_X is this solve's compact X(q) storage", "gravity is the gravity constant"],
                       "T *s_c, const T *s_qd, const T *s_qdd, const T *s_X, const T gravity")
     _emit_link_setup(self)
-    self.gen_add_code_line("const T qdd = (s_qdd != nullptr) ? s_qdd[lane] : static_cast<T>(0);")
+    self.gen_add_code_line("const T qdd = (s_qdd != nullptr && lane < %d) ? s_qdd[lane] : static_cast<T>(0);" % n)
     _emit_force_only(self, True)
     self.gen_add_code_line("if (lane < %d) { s_c[lane] = grid_dot6(S, fC) + Lc[10]*qd; }" % n)
     self.gen_add_end_function()
@@ -714,7 +714,7 @@ def gen_inverse_dynamics_gradient_inner_tip(self, use_thread_group=False):
                       "T *s_dc_du, const T *s_qd, const T *s_qdd, T *s_X, const T gravity")
     self.gen_add_sync(use_thread_group)  # every lane is done with s_X before the hand-off records overwrite it
     _emit_link_setup(self)
-    self.gen_add_code_line("const T qdd = s_qdd[lane];")
+    self.gen_add_code_line("const T qdd = (lane < %d) ? s_qdd[lane] : static_cast<T>(0);" % self.model.n)
     _emit_bias(self, True)
     _emit_assembly(self, s_G="s_X", dst="s_dc_du", minv=None)
     self.gen_add_end_function()

@@ -358,3 +358,30 @@ def test_fdsva_so_matches_the_restated_reference_algorithm(name, torch_cuda, lib
         ref = fdsva_so(so, Minv, df_du).reshape(4, n, n, n)
         for t in range(4):
             assert np.abs(got[k].reshape(4, n, n, n)[t] - ref[t]).max() <= TOL * max(np.abs(ref[t]).max(), 1e-3), (k, t)
+
+
+def test_large_batch_component_kernels_after_lds_reuse(torch_cuda, libs):
+    """Regression: lanes of a lane group that hold no joint once read uninitialised LDS as their qdd; 0 * NaN then leaked into every joint's
+    composite sums.  It only showed with large batches (LDS re-used by many blocks): 65536 solves of ID and ID-gradient after other kernels ran."""
+    from oracle.rbd_oracle import Oracle
+
+    torch = torch_cuda
+    robot = RobotModel.from_fixture("iiwa14")
+    n, N = robot.n, 65536
+    lib = GridLibrary(build_library("iiwa14"), device=0, max_timesteps=N)
+    st = torch.cuda.current_stream().cuda_stream
+    rng = np.random.default_rng(77)
+    x = np.hstack([rng.uniform(-np.pi, np.pi, (N, n)), rng.uniform(-2, 2, (N, n)), rng.uniform(-10, 10, (N, n))]).astype(np.float32)
+    qdd = rng.uniform(-5, 5, (N, n)).astype(np.float32)
+    d_x, d_qdd = torch.from_numpy(x).cuda(), torch.from_numpy(qdd).cuda()
+    junk = torch.empty((N, 2 * n * n), dtype=torch.float32, device="cuda")
+    lib.forward_dynamics_gradient_device(d_x, N, junk, stream=st)  # leaves arbitrary bit patterns in LDS
+    c = torch.empty((N, n), dtype=torch.float32, device="cuda")
+    lib.inverse_dynamics_device(d_x, d_qdd, N, c, stream=st)
+    g = torch.empty((N, 2 * n * n), dtype=torch.float32, device="cuda")
+    lib.inverse_dynamics_gradient_device(d_x, d_qdd, N, g, stream=st)
+    torch.cuda.synchronize()
+    orc = Oracle(robot)
+    assert per_solve_err(c.cpu().numpy(), orc.rnea_batch(x.astype(np.float64), qdd.astype(np.float64))) <= TOL
+    assert per_solve_err(g.cpu().numpy(), orc.rnea_grad_batch(x.astype(np.float64), qdd.astype(np.float64))) <= TOL
+    lib.close()
