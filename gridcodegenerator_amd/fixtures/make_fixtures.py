@@ -11,6 +11,7 @@ No URDF files ship with the reference and URDFParser is not in the build contain
   * mixed5  - 5-DoF branched robot with prismatic joints (edge cases for joint models)
   * arm6    - 6-DoF serial chain, revolute joints about mixed axes, oblique joint frames, full inertia tensors (synthetic)
   * chain12 - 12-DoF serial chain, revolute joints about mixed axes (lane group of 16; synthetic)
+  * chain8  - 8-DoF serial chain: exactly as many joints as lanes in the lane group (no spare lane; synthetic)
 Run once; the JSON files are committed.
 """
 import json
@@ -133,10 +134,10 @@ def arm6():
     return dict(name="arm6", base_link="base", joints=joints)
 
 
-def chain12():
-    rng = np.random.default_rng(20261004)
+def chain12(count=12, seed=20261004, name="chain12"):
+    rng = np.random.default_rng(seed)
     joints = []
-    for i in range(12):
+    for i in range(count):
         scale = 0.25 * (0.9 ** i)
         mass = round(6.0 * (0.8 ** i), 4)
         com = np.round(rng.uniform(-0.4, 0.4, 3) * scale, 4)
@@ -144,14 +145,18 @@ def chain12():
         off = np.round(0.1 * float(d.min()) * rng.uniform(-1, 1, 3), 7)
         xyz = np.round(rng.uniform(-1, 1, 3) * scale, 4)
         rpy = [0.0, 0.0, 0.0] if i % 3 == 0 else np.round(rng.uniform(-0.6, 0.6, 3), 3).tolist()
-        joints.append(dict(name="chain12_joint_%d" % (i + 1), type="revolute", axis="zxy"[i % 3], parent_link="base" if i == 0 else "chain12_link_%d" % i,
+        joints.append(dict(name="%s_joint_%d" % (name, i + 1), type="revolute", axis="zxy"[i % 3], parent_link="base" if i == 0 else "%s_link_%d" % (name, i),
                            xyz=xyz.tolist(), rpy=rpy, damping=[0.0, 0.1][i % 2], limits=[-3.1, 3.1],
-                           link=link("chain12_link_%d" % (i + 1), mass, com.tolist(), d.tolist(), off.tolist())))
-    return dict(name="chain12", base_link="base", joints=joints)
+                           link=link("%s_link_%d" % (name, i + 1), mass, com.tolist(), d.tolist(), off.tolist())))
+    return dict(name=name, base_link="base", joints=joints)
+
+
+def chain8():
+    return chain12(8, 20261005, "chain8")
 
 
 if __name__ == "__main__":
-    for fn in (iiwa14, hyq, atlas, mixed5, arm6, chain12):
+    for fn in (iiwa14, hyq, atlas, mixed5, arm6, chain12, chain8):
         d = fn()
         with open(os.path.join(HERE, d["name"] + ".json"), "w") as f:
             json.dump(d, f, indent=1)

@@ -32,6 +32,7 @@ CASES = [  # (golden name, fixture, number of states, zero the damping?)
     ("mixed5", "mixed5", 8, False),
     ("arm6", "arm6", 8, False),
     ("chain12", "chain12", 8, False),
+    ("chain8", "chain8", 8, False),
 ]
 
 

@@ -29,7 +29,7 @@ def libs():
     return get
 
 
-@pytest.mark.parametrize("name", ["iiwa14", "hyq", "atlas", "mixed5", "arm6", "chain12"])
+@pytest.mark.parametrize("name", ["iiwa14", "hyq", "atlas", "mixed5", "arm6", "chain12", "chain8"])
 def test_emulated_fd_grad_matches_goldens(name, libs, golden):
     g = golden(name)
     lib = libs(name)
@@ -109,7 +109,7 @@ def test_emulated_empty_batch_is_a_noop(libs):
     assert out.shape == (0, 98)
 
 
-@pytest.mark.parametrize("name", ["iiwa14", "hyq", "atlas", "mixed5", "arm6", "chain12"])
+@pytest.mark.parametrize("name", ["iiwa14", "hyq", "atlas", "mixed5", "arm6", "chain12", "chain8"])
 def test_emulated_component_kernels(name, libs, golden):
     g = golden(name)
     lib = libs(name)
@@ -184,7 +184,7 @@ def test_emulated_error_behaviour(libs):
     assert np.isfinite(out).all()
 
 
-@pytest.mark.parametrize("name", ["iiwa14", "arm6"])
+@pytest.mark.parametrize("name", ["iiwa14", "arm6", "chain8"])
 def test_emulated_idsva_so(name, libs, golden):
     """second-order derivatives of inverse dynamics, against the NumPy restatement of the reference's emitter
     (oracle/idsva_so_oracle.py; parity unpinned - the reference holds no vectors for it, see that module)."""

@@ -11,7 +11,7 @@ from gridcodegenerator_amd.runtime import build_library, GridLibrary
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-4
-ROBOTS = ["iiwa14", "hyq", "atlas", "mixed5", "arm6", "chain12"]
+ROBOTS = ["iiwa14", "hyq", "atlas", "mixed5", "arm6", "chain12", "chain8"]
 
 
 @pytest.fixture(scope="module")
@@ -67,7 +67,7 @@ def test_fd_grad_matches_reference_goldens(name, torch_cuda, libs, golden):
     assert per_solve_err(out, ref) <= TOL
 
 
-@pytest.mark.parametrize("name,N", [("iiwa14", 1), ("iiwa14", 37), ("iiwa14", 1024), ("hyq", 4096), ("atlas", 257), ("mixed5", 100), ("arm6", 333), ("chain12", 129)])
+@pytest.mark.parametrize("name,N", [("iiwa14", 1), ("iiwa14", 37), ("iiwa14", 1024), ("hyq", 4096), ("atlas", 257), ("mixed5", 100), ("arm6", 333), ("chain12", 129), ("chain8", 1000)])
 def test_fd_grad_matches_oracle_on_seeded_inputs(name, N, torch_cuda, libs):
     from oracle.rbd_oracle import Oracle
 
@@ -139,7 +139,7 @@ def test_full_batch_16384_properties(torch_cuda, libs):
     assert (np.abs(got - fd) / scale).max() < 5e-2  # fp32 finite differences are crude; this catches layout/sign errors
 
 
-@pytest.mark.parametrize("name", ["iiwa14", "hyq", "atlas", "mixed5", "arm6", "chain12"])
+@pytest.mark.parametrize("name", ["iiwa14", "hyq", "atlas", "mixed5", "arm6", "chain12", "chain8"])
 def test_component_kernels_match_goldens(name, torch_cuda, libs, golden):
     """inverse_dynamics, direct_minv, forward_dynamics, inverse_dynamics_gradient."""
     torch = torch_cuda
@@ -283,7 +283,7 @@ def test_non_default_generation_variants_on_gpu(env, torch_cuda, golden, tmp_pat
     lib.close()
 
 
-@pytest.mark.parametrize("name", ["iiwa14", "arm6", "chain12"])
+@pytest.mark.parametrize("name", ["iiwa14", "arm6", "chain12", "chain8"])
 def test_idsva_so_matches_the_restated_reference_algorithm(name, torch_cuda, libs, golden):
     """SURVEY.md section 8(f) rank 3 (serial revolute chains): second-order inverse-dynamics derivatives on the GPU vs the NumPy restatement of the
     reference's emitter (oracle/idsva_so_oracle.py - parity unpinned, anchored on finite differences of the pinned first-order oracle)."""
@@ -328,7 +328,7 @@ def test_idsva_so_is_refused_for_branched_robots(torch_cuda, libs):
         lib.idsva_so_device(torch.zeros((1, 36), device="cuda"), None, 1, torch.zeros((1, 4 * 12 ** 3), device="cuda"))
 
 
-@pytest.mark.parametrize("name", ["iiwa14", "arm6", "chain12"])
+@pytest.mark.parametrize("name", ["iiwa14", "arm6", "chain12", "chain8"])
 def test_fdsva_so_matches_the_restated_reference_algorithm(name, torch_cuda, libs, golden):
     """Second half of SURVEY.md section 8(f) rank 3 (serial revolute chains): second-order forward-dynamics derivatives on the GPU vs the NumPy
     restatements of the reference's idsva_so + fdsva_so emitters fed by the pinned first-order oracle (parity unpinned)."""
