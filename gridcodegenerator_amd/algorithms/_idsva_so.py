@@ -14,8 +14,10 @@ joint (crm/crf/icrf matrices, D1..D4, outer products t1..t9, p1..p6, :473-911) a
   * the reference's "=" / "+=" phases are merged into ONE complete value per output entry (checked entry by entry against the literal
     restatement oracle/idsva_so_oracle.py by the tests), so every entry is written exactly once and no read-modify-write is needed.  The
     structurally zero entries of dM_dq (dM_ik/dq_j with j <= min(i, k)) are written by their owner lane first.  The kernels stage the
-    4 n^3 record in LDS behind a compact slice and copy it out with coalesced 16-byte stores (direct scattered 4-byte stores: 145 us per
-    16384 solves, of which 31 us arithmetic); the device function writes through whatever pointer it is given.
+    4 n^3 record in LDS behind a compact slice and copy it out with coalesced 16-byte stores: 106 us per 16384 solves, of which 31 us
+    arithmetic (LDS capacity allows 0.75 waves per SIMD).  Storing straight to global memory is store-issue bound however the entries are
+    grouped (measured): all as 4-byte stores 145 us; the rows whose first index is the lane's joint collected into 16-byte pieces 121 us -
+    every store instruction still moves at most 28 bytes per solve.  The device function writes through whatever pointer it is given.
 
 Parity: the reference ships no oracle or vectors for this algorithm (PARITY UNPINNED); the tests compare with the NumPy restatement of
 the reference's emitter, which is itself anchored on finite differences of the pinned first-order oracle.
