@@ -385,3 +385,47 @@ def test_large_batch_component_kernels_after_lds_reuse(torch_cuda, libs):
     assert per_solve_err(c.cpu().numpy(), orc.rnea_batch(x.astype(np.float64), qdd.astype(np.float64))) <= TOL
     assert per_solve_err(g.cpu().numpy(), orc.rnea_grad_batch(x.astype(np.float64), qdd.astype(np.float64))) <= TOL
     lib.close()
+
+
+def test_generated_host_api_of_a_chain_first_and_second_order_float_and_double(torch_cuda, golden, tmp_path):
+    """The generated host API of a serial-chain robot (tip-frame path) for T = float and T = double: forward_dynamics_gradient<T>, forward_dynamics<T>,
+    idsva_so_host<T, true>, fdsva_so<T>.  The double instantiations must agree with the fp64 oracles to rounding level - that pins the generated
+    algorithms (incl. the DPP scans on 64-bit values and the register factorisation) independently of fp32 effects."""
+    import os
+    import shutil
+    import subprocess
+
+    from gridcodegenerator_amd.robot import DuckRobot
+    from gridcodegenerator_amd.runtime import HIPCC_FLAGS, generate_header
+    from oracle.fdsva_so_oracle import fdsva_so
+    from oracle.idsva_so_oracle import idsva_so
+    from oracle.rbd_oracle import Oracle
+
+    name = "iiwa14"
+    g = golden(name)
+    n, N = g["q"].shape[1], 4
+    gen_dir = tmp_path / "gen"
+    generate_header(RobotModel.from_fixture(name), str(gen_dir))
+    exe = str(tmp_path / "host_api_so_demo")
+    flags = [f for f in HIPCC_FLAGS if f not in ("-shared", "-fPIC")]
+    src = os.path.join(os.path.dirname(os.path.abspath(__file__)), "cpp", "host_api_so_demo.hip")
+    subprocess.check_call([shutil.which("hipcc") or "/opt/rocm/bin/hipcc"] + flags + ["-I" + str(gen_dir), src, "-o", exe])
+    x = np.hstack([g["q"], g["qd"], g["u"]]).astype(np.float64)[:N]
+    (tmp_path / "in.bin").write_bytes(x.tobytes())
+    out = subprocess.check_output([exe, str(tmp_path / "in.bin"), str(N), str(tmp_path / "o")], text=True)
+    assert "done" in out
+    robot = RobotModel.from_fixture(name)
+    model, orc = DuckRobot(robot), Oracle(robot)
+    load = lambda tag, what: np.frombuffer((tmp_path / ("o_%s_%s.bin" % (tag, what))).read_bytes(), dtype=np.float64).reshape(N, -1)
+    for tag, tol in (("f32", TOL), ("f64", 1e-9)):
+        dfdu, so, df2 = load(tag, "dfdu"), load(tag, "so"), load(tag, "df2")
+        assert per_solve_err(dfdu, np.stack([g["df_du"][k].T.reshape(-1) for k in range(N)])) <= tol
+        for k in range(N):
+            q, qd, u = (x[k, i * n:(i + 1) * n] for i in range(3))
+            df_du, qdd, Minv, _ = orc.fd_grad(q, qd, u, full=True)
+            ref_so = np.concatenate([t.reshape(-1) for t in idsva_so(model, q, qd, qdd)])
+            ref_df2 = fdsva_so(ref_so, Minv, df_du)
+            for got, ref in ((so[k], ref_so), (df2[k], ref_df2)):
+                for t in range(4):
+                    a, b = got.reshape(4, -1)[t], ref.reshape(4, -1)[t]
+                    assert np.abs(a - b).max() <= tol * max(np.abs(b).max(), 1e-3), (tag, k, t)
