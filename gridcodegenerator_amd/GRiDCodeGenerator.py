@@ -290,6 +290,18 @@ class GRiDCodeGenerator:
                       "    __global__ forward_dynamics_gradient_kernel<T>(T *d_df_du, const T *d_q_qd, const int stride_q_qd, const T *d_qdd, const T *d_Minv, const robotModel<T> *d_robotModel, const T gravity, const int NUM_TIMESTEPS)",
                       "    __host__   forward_dynamics_gradient<T,USE_QDD_MINV_FLAG=false>(gridData<T> *hd_data, const robotModel<T> *d_robotModel, const T gravity, const int num_timesteps, const dim3 block_dimms, const dim3 thread_dimms, hipStream_t *streams)",
                       "",
+                      "    __device__ aba_device<T>(T *s_qdd, const T *s_q, const T *s_qd, const T *s_tau, T *s_work, const robotModel<T> *d_robotModel, const T gravity, const int lane)",
+                      "    __global__ aba_kernel<T>(T *d_qdd, const T *d_q_qd_tau, const int stride_q_qd, const robotModel<T> *d_robotModel, const T gravity, const int NUM_TIMESTEPS)",
+                      "    __host__   aba<T>(gridData<T> *hd_data, const robotModel<T> *d_robotModel, const T gravity, const int num_timesteps, const dim3 block_dimms, const dim3 thread_dimms, hipStream_t *streams)",
+                      ""] + ([
+                      "    second order (this robot is a serial revolute chain; launch with IDSVA_SO_/FDSVA_SO_SUGGESTED_THREADS threads and the matching *_DYNAMIC_SHARED_MEM_COUNT):",
+                      "    __device__ idsva_so_device<T>(T *so, const T *s_q, const T *s_qd, [const T *s_qdd,] T *s_scratch, const robotModel<T> *d_robotModel, const T gravity, const int lane, const bool active)",
+                      "    __global__ idsva_so_kernel<T>(T *d_idsva_so, const T *d_q_qd_u, const int stride_q_qd_u, [const T *d_qdd,] const robotModel<T> *d_robotModel, const T gravity, const int NUM_TIMESTEPS)",
+                      "    __host__   idsva_so_host<T,USE_QDD_FLAG=false>(gridData<T> *hd_data, const robotModel<T> *d_robotModel, const T gravity, const int num_timesteps, const dim3 block_dimms, const dim3 thread_dimms, hipStream_t *streams)",
+                      "    __device__ fdsva_so_device<T>(T *df2, T *s_df_du, T *s_idsva_so, const T *s_q, const T *s_qd, const T *s_u, T *s_work, const robotModel<T> *d_robotModel, const T gravity, const int lane, const bool active)",
+                      "    __global__ fdsva_so_kernel<T>(T *d_df2, const T *d_q_qd_u, const int stride_q_qd_u, const robotModel<T> *d_robotModel, const T gravity, const int NUM_TIMESTEPS)",
+                      "    __host__   fdsva_so<T>(gridData<T> *hd_data, const robotModel<T> *d_robotModel, const T gravity, const int num_timesteps, const dim3 block_dimms, const dim3 thread_dimms, hipStream_t *streams)",
+                      ""] if self.gen_idsva_so_available() else []) + [
                       "Every host function also exists as NAME_single_timing and NAME_compute_only (no streams argument).",
                       "",
                       "Execution model (differs from the CUDA original by design): a lane group of GRID_LANES_PER_SOLVE = " + str(self.lanes_per_solve) + " consecutive lanes of one",
