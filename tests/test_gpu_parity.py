@@ -358,6 +358,14 @@ def test_fdsva_so_matches_the_restated_reference_algorithm(name, torch_cuda, lib
         ref = fdsva_so(so, Minv, df_du).reshape(4, n, n, n)
         for t in range(4):
             assert np.abs(got[k].reshape(4, n, n, n)[t] - ref[t]).max() <= TOL * max(np.abs(ref[t]).max(), 1e-3), (k, t)
+    # ragged batch on a grid smaller than the batch (grid-stride, partially filled last trip): bit-identical records
+    M = N - 3
+    lib.set_launch_dims(1, 32)
+    out2 = torch.full((M, 4 * n ** 3), float("nan"), dtype=torch.float32, device="cuda")
+    lib.fdsva_so_device(torch.from_numpy(xh[:M]).cuda(), M, out2, stream=st)
+    torch.cuda.synchronize()
+    lib.set_launch_dims(0, 0)
+    assert np.array_equal(out2.cpu().numpy(), got[:M])
 
 
 def test_large_batch_component_kernels_after_lds_reuse(torch_cuda, libs):
