@@ -41,3 +41,27 @@ def test_bench_line_schema_is_complete():
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
                 "data", "config", "roofline", "cpu_baseline", "bound", "achieved", "peak", "frac", "traffic", "cores", "kind", "sample"):
         assert '"%s"' % key in src, key
+
+
+import pytest  # noqa: E402
+
+
+@pytest.mark.gpu
+def test_two_rank_bench_rehearsal_on_one_gpu():
+    """The REAL multi-rank code path of bench.py (per-rank shard, library per rank, opening barrier, K launches, per-rank clock stop, MAX-reduce, one JSON
+    line) with two ranks sharing the one GPU of the test box: GRID_BENCH_REHEARSAL=1 swaps RCCL for gloo, nothing else."""
+    port = free_port()
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), GRID_BENCH_REHEARSAL="1")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "100", "--warmup", "10"],
+                                      env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=300) for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    lines0 = [l for l in outs[0][0].splitlines() if l.startswith("{")]
+    assert len(lines0) == 1 and not [l for l in outs[1][0].splitlines() if l.startswith("{")]
+    d = json.loads(lines0[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 100 and d["scaling"] == "weak" and d["cpu_baseline"] is None
+    assert d["config"]["global_batch"] == 2 * 16384
+    assert abs(d["value"] - 2 * 16384 * 100 / (d["ms_per_step"] * 1e-3 * 100)) <= 1e-6 * d["value"]
+    assert d["value"] > 1e8
