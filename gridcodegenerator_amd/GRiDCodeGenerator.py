@@ -45,7 +45,9 @@ class GRiDCodeGenerator:
         gen_forward_dynamics_gradient_host, gen_forward_dynamics_gradient, gen_forward_dynamics_gradient_device_function_call, \
         gen_tip_frame_link_constants, gen_tip_frame_joint_offset, gen_tip_frame_library, gen_forward_dynamics_gradient_inner_tip, \
         gen_forward_dynamics_gradient_inner_tip_function_call, gen_tip_frame_gradient, \
-        gen_inverse_dynamics_inner_tip, gen_inverse_dynamics_gradient_inner_tip, gen_forward_dynamics_inner_tip, gen_direct_minv_inner_tip, gen_tip_frame_components
+        gen_inverse_dynamics_inner_tip, gen_inverse_dynamics_gradient_inner_tip, gen_forward_dynamics_inner_tip, gen_direct_minv_inner_tip, gen_tip_frame_components, \
+        gen_branch_frame_plan, gen_branch_frame_constants, gen_branch_frame_library, gen_forward_dynamics_gradient_inner_branch, \
+        gen_forward_dynamics_gradient_inner_branch_function_call
 
     # NumPy debug helpers with the reference's names and signatures (reference GRiDCodeGenerator.py:50-51, README "Additional Features")
     from ._test import test_rnea, test_minv, test_rnea_grad, test_fd_grad
@@ -81,8 +83,8 @@ class GRiDCodeGenerator:
         depth_max = max(self.model.depth) + 1
         nslots = len(self.gen_gradient_slots())
         mode = _os.environ.get("GRID_GRADIENT_WALK", "auto")
-        if mode not in ("auto", "registers", "lds", "tipframe"):
-            raise ValueError("GRID_GRADIENT_WALK must be auto, registers, lds or tipframe")
+        if mode not in ("auto", "registers", "lds", "tipframe", "branch"):
+            raise ValueError("GRID_GRADIENT_WALK must be auto, registers, lds, tipframe or branch")
         self.register_walk = (mode == "registers") or (mode in ("auto", "tipframe") and depth_max * 6 * (1 + nslots) <= 200)
         # forward_dynamics_gradient of serial revolute chains is assembled in the tip link's frame (algorithms/_tip_frame_gradient.py);
         # every other robot, and every other kernel, uses the column walk selected above
@@ -96,6 +98,14 @@ class GRiDCodeGenerator:
         if mode == "tipframe" and not tip_ok:
             raise NotImplementedError("GRID_GRADIENT_WALK=tipframe needs a serial chain of revolute joints (or a forest of equal such chains) with at most 16 joints")
         self.tip_frame = tip_ok and mode in ("auto", "tipframe") and not DEBUG_MODE  # (DEBUG_MODE prints M^-1, which this path never forms)
+        # branched robots with revolute joints: forward_dynamics_gradient with every branch in the frame of its own tip link
+        # (algorithms/_branch_frame_gradient.py); the other kernels of such robots stay on the column walk
+        self.branch_plan = self.gen_branch_frame_plan() if (COLS_PER_LANE == 2 and not DEBUG_MODE and not self.tip_frame and mode in ("auto", "branch")) else None
+        if mode == "branch" and self.branch_plan is None:
+            raise NotImplementedError("GRID_GRADIENT_WALK=branch needs revolute joints and branches that fit the 16-lane rows of the lane group")
+        self.branch_frame = self.branch_plan is not None
+        if self.branch_frame:
+            self.tip_L = self.branch_plan["maxLb"]  # (length of the DPP scans)
         self.reuse_rnea = self.register_walk and n <= 9 and _os.environ.get("GRID_FUSE_FD", "1") == "1" and _os.environ.get("GRID_REUSE_RNEA", "0") == "1"  # measured: 16.6 us vs 15.0 us per launch with re-use (extra LDS traffic on the critical path), so off by default
         # tuning knob: minimum waves per SIMD the register allocator must leave room for (second __launch_bounds__ argument); 0 = compiler's choice
         self.min_waves_per_eu = int(__import__("os").environ.get("GRID_MIN_WAVES", "0"))
@@ -160,6 +170,14 @@ class GRiDCodeGenerator:
                                  "// the *_DYNAMIC_SHARED_MEM_COUNT constants below are that amount for SUGGESTED_THREADS"])
         for k in ("IN", "X", "U", "T", "MINV", "QDD", "F", "J"):
             self.gen_add_code_line("const int GRID_OFF_" + k + " = " + str(lds[k]) + ";")
+        fd_threads = self.suggested_threads
+        if lds["FD_TOTAL"] < lds["TOTAL"]:  # LDS-capacity-bound kernels: one wave per block packs the CU's 160 KB best
+            fd_threads = 64
+        self.gen_add_code_lines(["// the forward_dynamics_gradient kernel with (q, qd, u) input carves slices of FD_DU_LDS_PER_SOLVE elements (a prefix-compatible subset of the",
+                                 "// general slice: same GRID_OFF_IN / GRID_OFF_X) and is best launched with FD_DU_SUGGESTED_THREADS threads per block",
+                                 "const int FD_DU_LDS_PER_SOLVE = " + str(lds["FD_TOTAL"]) + ";",
+                                 "const int FD_DU_OFF_SP = " + str(lds["FD_SP"]) + "; const int FD_DU_OFF_QDD = " + str(lds["FD_QDD"]) + ";",
+                                 "const int FD_DU_SUGGESTED_THREADS = " + str(fd_threads) + ";"])
         for k in ("ID", "MINV", "FD", "ABA", "ID_DU", "FD_DU"):
             self.gen_add_code_line("const int " + k + "_DYNAMIC_SHARED_MEM_COUNT = " + str(count) + ";")
         self.gen_add_code_lines(["const int ID_DU_MAX_SHARED_MEM_COUNT = " + str(count) + ";",
@@ -320,8 +338,10 @@ class GRiDCodeGenerator:
         self.gen_add_code_line("namespace " + self.file_namespace + " {", True)
         self.gen_add_constants_helpers(include_base_inertia, include_homogenous_transforms)
         self.gen_spatial_algebra_helpers()
-        if self.tip_frame:
+        if self.tip_frame or self.branch_frame:
             self.gen_tip_frame_library()
+        if self.branch_frame:
+            self.gen_branch_frame_library()
         self.gen_model_constant_table()
         self.gen_init_topology_helpers()
         self.gen_init_XImats(include_base_inertia, include_homogenous_transforms)
@@ -338,6 +358,8 @@ class GRiDCodeGenerator:
         self.gen_inverse_dynamics_gradient(use_thread_group)
         if self.tip_frame:
             self.gen_tip_frame_gradient(use_thread_group)
+        if self.branch_frame:
+            self.gen_forward_dynamics_gradient_inner_branch(use_thread_group)
         self.gen_forward_dynamics_gradient(use_thread_group)
         self.gen_idsva_so(use_thread_group)
         self.gen_fdsva_so(use_thread_group)

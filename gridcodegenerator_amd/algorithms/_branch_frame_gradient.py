@@ -1,0 +1,642 @@
+"""Forward-dynamics gradient for branched robots with revolute joints: every BRANCH of the tree in the frame of its own tip link.
+
+Generalises algorithms/_tip_frame_gradient.py (one frame for a serial chain) to kinematic trees; same function as the column walk
+(reference algorithms/_inverse_dynamics_gradient.py:27-775, _direct_minv.py:23-453, _forward_dynamics_gradient.py:7-62; oracle
+/root/reference/_test.py:229-520) and the same identities (Singh, Russell & Wensing, RA-L 2022; see the module notes of _tip_frame_gradient.py).
+
+Why one frame per branch: the identities hold in ANY single inertial frame, but fp32 only survives the later M^-1 amplification if the
+light distal links are described about a nearby origin (measured on the 7-DoF arm: 1.8e-4 in the world frame, 3e-6 in the tip frame).
+A tree has several tips, so every maximal unbranched run of joints (a branch) uses the frame F_b of ITS last link.
+
+  * lanes: the joints of a branch sit on consecutive lanes of one 16-lane DPP row (branches are bin-packed into the rows of the lane group,
+    so lane != joint id in general; a per-lane table row gives joint id, position, branch length, tree level, ...)
+  * frames: every lane walks the root path of its branch, tip -> root (wave-uniform per branch), with the rotation blocks of X(q):
+    it keeps the pose of its own link, the pose T_b of the parent branch's frame (for the hand-over below) and the joint axes S_i of ALL
+    joints on the path, expressed in F_b
+  * kinematics need no cross-lane traffic at all: v, a of the own link and Pd_i = v_i x S_i, Pdd_i of every ancestor i are running sums along
+    the path (root -> own joint), evaluated redundantly by the lanes in their own branch frame
+  * composites I^C (10), B^C (12), f^C (6): suffix DPP scan inside the branch, then from the deepest tree level upwards the total of a
+    branch is re-expressed in the parent branch's frame (T_b) and handed to ALL lanes of the parent branch through LDS
+  * entries: lane k (joint k) evaluates, in F_b, everything that couples k with its ancestors-or-self i:
+        M[i][k] = S_i . t1_k     dc_i/dq_k = S_i . t3_k     dc_i/dqd_k = S_i . t2_k      (column k, rows i)
+        dc_k/dq_i = t1_k . Pdd_i + t4_k . Pd_i      dc_k/dqd_i = 2 t1_k . Pd_i + t4_k . S_i      (row k, columns i != k)
+    into the (zero-filled) LDS image of dc/du and M; unrelated joints stay exactly zero
+  * M is never inverted: per base-rooted component the tree-sparse U D U^T factorisation (leaves first: no fill-in, Featherstone's
+    branch-induced sparsity) is evaluated wave-uniformly in registers, parked in LDS, and every lane solves for its two columns of dc/du.
+
+Scope: fixed-base robots whose joints are all revolute, branches of at most 16 joints that can be packed into the lane group's DPP rows.
+Everything else stays on the column walk; so do the stand-alone component kernels of such robots.
+"""
+import numpy as np
+
+
+
+
+def gen_branch_frame_plan(self):
+    """Decompose the tree into branches, pack them into DPP rows, derive the per-lane tables.  Returns None when the robot is out of scope."""
+    m = self.model
+    n = m.n
+    lanes = self.lanes_per_solve
+    if any(s_ >= 3 for s_ in m.S_index):
+        return None
+    parent = list(m.parent)
+    ch = [list(m.children[j]) for j in range(n)]
+    br = [-1] * n
+    branches = []
+    for j in range(n):
+        p = parent[j]
+        if p < 0 or len(ch[p]) >= 2:
+            br[j] = len(branches)
+            branches.append([j])
+        else:
+            if p != j - 1:
+                return None  # ids are DFS pre-order: an only child follows its parent immediately
+            br[j] = br[p]
+            branches[br[j]].append(j)
+    nb = len(branches)
+    pb = [(-1 if parent[J[0]] < 0 else br[parent[J[0]]]) for J in branches]
+    level = [0] * nb
+    for b in range(nb):
+        if pb[b] >= 0:
+            level[b] = level[pb[b]] + 1
+    paths = []
+    for J in branches:
+        path, j = [], J[-1]
+        while j >= 0:
+            path.append(j)
+            j = parent[j]
+        paths.append(path)
+    rowcap = min(16, lanes)
+    if max(len(J) for J in branches) > rowcap:
+        return None
+    rows = [[] for _ in range(lanes // rowcap)]
+    for b in sorted(range(nb), key=lambda b_: (-len(branches[b_]), b_)):  # first-fit decreasing
+        for r in rows:
+            if sum(len(branches[x]) for x in r) + len(branches[b]) <= rowcap:
+                r.append(b)
+                break
+        else:
+            return None
+    joint_of_lane = [-1] * lanes
+    for ri, r in enumerate(rows):
+        at = ri * rowcap
+        for b in sorted(r):
+            for j in branches[b]:
+                joint_of_lane[at] = j
+                at += 1
+    kids = [[c for c in range(nb) if pb[c] == b] for b in range(nb)]
+    # base-rooted components (contiguous id ranges) and their shapes
+    comp_base = [0] * n
+    for j in range(n):
+        comp_base[j] = j if parent[j] < 0 else comp_base[parent[j]]
+    comps = sorted(set(comp_base))
+    shapes, shape_of = [], {}
+    for cb in comps:
+        size = len(m.subtree[cb])
+        sig = tuple((parent[cb + i] - cb if parent[cb + i] >= 0 else -1) for i in range(size))
+        if sig not in shapes:
+            shapes.append(sig)
+        shape_of[cb] = shapes.index(sig)
+    D = max(len(p_) for p_ in paths)
+    maxchild = max([len(k_) for k_ in kids] + [0])
+    row_len = (24 + D + max(maxchild, 1) + 3) // 4 * 4
+    # compact (tree-sparse) storage of M and of its factors: column k holds the entries of its ancestors (ascending) and then the diagonal
+    mstart, at = [0] * n, 0
+    for j in range(n):
+        mstart[j] = at
+        at += len(m.ancestors[j]) + 1
+    ubase = {cb: mstart[cb] for cb in comps}
+    nnz = at
+    if 2 * nnz + 28 * nb + 4 > 20 * n:
+        return None  # (M, its factors and the branch hand-over records live in the X(q) storage once the frames are known)
+    return dict(branches=branches, br=br, pb=pb, level=level, paths=paths, joint_of_lane=joint_of_lane, kids=kids, comp_base=comp_base,
+                shapes=shapes, shape_of=shape_of, D=D, maxLb=max(len(J) for J in branches), maxlevel=max(level), maxchild=maxchild, row_len=row_len, nb=nb, ubase=ubase, mstart=mstart, nnz=nnz)
+
+
+def gen_branch_frame_constants(self):
+    """Table rows appended to grid_model_constants: one row per lane
+    [Ic (6) | c (3) | m | damping | axis | joint id | pos | branch length | level | branch slot | component base | shape | path length | factor base of the component | start of the joint's column in the compact M | 2 spare |
+     path codes (4*joint + axis, tip -> root, -1 = none) x D | child branch slots (-1 = none) x maxchild], then 4 floats per joint: the joint offset."""
+    m = self.model
+    P = self.branch_plan
+    rows = []
+    for lane in range(self.lanes_per_solve):
+        j = P["joint_of_lane"][lane]
+        row = [0.0] * P["row_len"]
+        if j < 0:
+            row[12] = -1.0
+            row[18] = -1.0
+            for i in range(P["D"]):
+                row[24 + i] = -1.0
+            for c in range(max(P["maxchild"], 1)):
+                row[24 + P["D"] + c] = -1.0
+            rows += row
+            continue
+        I = m.I[j]
+        mass = I[3, 3]
+        H = I[:3, 3:]
+        h = np.array([H[2, 1], H[0, 2], H[1, 0]])
+        c = h / mass
+        Ic = I[:3, :3] - mass * (float(c @ c) * np.eye(3) - np.outer(c, c))
+        b = P["br"][j]
+        J = P["branches"][b]
+        row[:12] = [Ic[0, 0], Ic[0, 1], Ic[0, 2], Ic[1, 1], Ic[1, 2], Ic[2, 2], c[0], c[1], c[2], mass, float(m.damping[j]), float(m.S_index[j])]
+        row[12:20] = [float(j), float(J.index(j)), float(len(J)), float(P["level"][b]), float(b), float(P["comp_base"][j]),
+                      float(P["shape_of"][P["comp_base"][j]]), float(len(P["paths"][b]))]
+        row[20] = float(P["ubase"][P["comp_base"][j]])
+        row[21] = float(P["mstart"][j])
+        for i in range(P["D"]):
+            path = P["paths"][b]
+            row[24 + i] = float(4 * path[i] + m.S_index[path[i]]) if i < len(path) else -1.0
+        for c_ in range(max(P["maxchild"], 1)):
+            row[24 + P["D"] + c_] = float(P["kids"][b][c_]) if c_ < len(P["kids"][b]) else -1.0
+        rows += row
+    for j in range(m.n):
+        r = self.gen_tip_frame_joint_offset(j)
+        rows += [r[0], r[1], r[2], 0.0]
+    return rows
+
+
+_BRANCH_LIBRARY = r"""
+// ---------------------------------------------------------------------------------------------------------------------
+// branch-frame gradient path (trees of revolute joints): hand-over of composite quantities from a branch frame to its parent's
+// ---------------------------------------------------------------------------------------------------------------------
+// y = R^T x  (R maps parent-frame coordinates to branch-frame coordinates)
+template <typename T>
+__device__ __forceinline__ void grid_rt3(T *y, const T (&R)[9], const T x0, const T x1, const T x2) {
+    y[0] = R[0]*x0 + R[3]*x1 + R[6]*x2;
+    y[1] = R[1]*x0 + R[4]*x1 + R[7]*x2;
+    y[2] = R[2]*x0 + R[5]*x1 + R[8]*x2;
+}
+// y = R^T A R for symmetric A = [xx xy xz yy yz zz]
+template <typename T>
+__device__ __forceinline__ void grid_rt_sym(T *y, const T (&R)[9], const T (&A)[6]) {
+    T W[9];
+    #pragma unroll
+    for (int c = 0; c < 3; c++) {
+        W[c]     = A[0]*R[c] + A[1]*R[3 + c] + A[2]*R[6 + c];
+        W[3 + c] = A[1]*R[c] + A[3]*R[3 + c] + A[4]*R[6 + c];
+        W[6 + c] = A[2]*R[c] + A[4]*R[3 + c] + A[5]*R[6 + c];
+    }
+    y[0] = R[0]*W[0] + R[3]*W[3] + R[6]*W[6];
+    y[1] = R[0]*W[1] + R[3]*W[4] + R[6]*W[7];
+    y[2] = R[0]*W[2] + R[3]*W[5] + R[6]*W[8];
+    y[3] = R[1]*W[1] + R[4]*W[4] + R[7]*W[7];
+    y[4] = R[1]*W[2] + R[4]*W[5] + R[7]*W[8];
+    y[5] = R[2]*W[2] + R[5]*W[5] + R[8]*W[8];
+}
+// force vector [n; f] about the origin of the branch frame -> about the origin p of the parent's frame, in the parent's coordinates
+template <typename T>
+__device__ __forceinline__ void grid_force_up(T *y, const T (&R)[9], const T (&p)[3], const T (&f)[6]) {
+    grid_rt3(y, R, f[0] - (p[1]*f[5] - p[2]*f[4]), f[1] - (p[2]*f[3] - p[0]*f[5]), f[2] - (p[0]*f[4] - p[1]*f[3]));
+    grid_rt3(y + 3, R, f[3], f[4], f[5]);
+}
+// composite inertia (10), Coriolis matrix (12) and force (6) of a whole branch, re-expressed in the parent branch's frame: y[28]
+template <typename T>
+__device__ __forceinline__ void grid_junction_up(T (&y)[28], const T (&R)[9], const T (&p)[3], const T (&I)[10], const T (&B)[12], const T (&f)[6]) {
+    {   // inertia: origin shift (c' = c - p), then rotation
+        const T m = I[9];
+        const T s = static_cast<T>(-2)*(I[6]*p[0] + I[7]*p[1] + I[8]*p[2]) + m*(p[0]*p[0] + p[1]*p[1] + p[2]*p[2]);
+        T A[6];
+        A[0] = I[0] + s + static_cast<T>(2)*I[6]*p[0] - m*p[0]*p[0];
+        A[1] = I[1] + I[6]*p[1] + p[0]*I[7] - m*p[0]*p[1];
+        A[2] = I[2] + I[6]*p[2] + p[0]*I[8] - m*p[0]*p[2];
+        A[3] = I[3] + s + static_cast<T>(2)*I[7]*p[1] - m*p[1]*p[1];
+        A[4] = I[4] + I[7]*p[2] + p[1]*I[8] - m*p[1]*p[2];
+        A[5] = I[5] + s + static_cast<T>(2)*I[8]*p[2] - m*p[2]*p[2];
+        grid_rt_sym(&y[0], R, A);
+        grid_rt3(&y[6], R, I[6] - m*p[0], I[7] - m*p[1], I[8] - m*p[2]);
+        y[9] = m;
+    }
+    {   // Coriolis matrix [Sym | n | l]: Sym' = Sym + l p^T + p l^T - 2 (p.l) 1,  n' = n - p x l,  l' = l
+        const T l0 = B[9], l1 = B[10], l2 = B[11];
+        const T s = static_cast<T>(-2)*(p[0]*l0 + p[1]*l1 + p[2]*l2);
+        T A[6];
+        A[0] = B[0] + s + static_cast<T>(2)*l0*p[0];
+        A[1] = B[1] + l0*p[1] + p[0]*l1;
+        A[2] = B[2] + l0*p[2] + p[0]*l2;
+        A[3] = B[3] + s + static_cast<T>(2)*l1*p[1];
+        A[4] = B[4] + l1*p[2] + p[1]*l2;
+        A[5] = B[5] + s + static_cast<T>(2)*l2*p[2];
+        grid_rt_sym(&y[10], R, A);
+        grid_rt3(&y[16], R, B[6] - (p[1]*l2 - p[2]*l1), B[7] - (p[2]*l0 - p[0]*l2), B[8] - (p[0]*l1 - p[1]*l0));
+        grid_rt3(&y[19], R, l0, l1, l2);
+    }
+    grid_force_up(&y[22], R, p, f);
+}
+"""
+
+
+def gen_branch_frame_library(self):
+    for line in _BRANCH_LIBRARY.strip("\n").split("\n"):
+        self.gen_add_code_line(line)
+    self.gen_add_code_line("")
+
+
+def _anc_local(sig):
+    """Strict ancestors (local indices, ascending) of every joint of a component with parent signature sig."""
+    out = []
+    for k in range(len(sig)):
+        a, p = [], sig[k]
+        while p >= 0:
+            a.append(p)
+            p = sig[p]
+        out.append(sorted(a))
+    return out
+
+
+def gen_forward_dynamics_gradient_inner_branch(self, use_thread_group=False):
+    """The fused inner of the branch-frame path (u-input form): see the module notes."""
+    m = self.model
+    n = m.n
+    P = self.branch_plan
+    D, maxLb, maxlevel, maxchild, RL = P["D"], P["maxLb"], P["maxlevel"], P["maxchild"], P["row_len"]
+    lanes = self.lanes_per_solve
+    ld = self.minv_ld
+    tab = 54 * n
+    roff = tab + RL * lanes
+    H = 24
+    A = self.gen_add_code_line
+    self.gen_add_func_doc("Computes the gradient of forward dynamics, every branch of the tree in the frame of its tip link",
+                          ["robots whose joints are all revolute (see the module notes of algorithms/_branch_frame_gradient.py); same results as",
+                           "direct_minv_inner + inverse_dynamics_inner + inverse_dynamics_gradient_inner",
+                           "s_df_du receives -Minv*dc/du in the device layout [col*n + row]; the caller must grid_wave_sync() before other lanes read it"],
+                          ["s_df_du is a pointer to LDS for the final result of size 2*NUM_JOINTS*NUM_JOINTS = " + str(2 * n * n) + " (also the assembly area of dc/du)",
+                           "s_qd is the vector of joint velocities in LDS", "s_u is the vector of joint input torques in LDS",
+                           "s_X is this solve's compact X(q) storage (the rotation blocks are read; once the frames are known it is re-used for the",
+                           "     tree-sparse M, its factors and the branch hand-over records)",
+                           "s_SP is LDS scratch for the joint axes along the root path of every branch (6 values per path joint)",
+                           "s_qdd is LDS scratch for tau - c and then the joint accelerations",
+                           "d_robotModel is the pointer to the initialized model specific helpers on the GPU", "gravity is the gravity constant",
+                           "lane is the caller's lane index inside the solve's lane group"], None)
+    A("template <typename T>")
+    A("__device__ __forceinline__")
+    A("void forward_dynamics_gradient_inner_branch(T *s_df_du, const T *s_qd, const T *s_u, T *s_X, T *s_SP, T *s_qdd, const robotModel<T> *d_robotModel, const T gravity, const int lane) {", True)
+    import os
+    ts_mode = os.environ.get("GRID_DEBUG_STOP", "0") == "20"  # profiling build: per-wave cycle stamps at the phase boundaries replace the first outputs
+
+    def TS(i):
+        if ts_mode:
+            A("asm volatile(\"s_waitcnt vmcnt(0) lgkmcnt(0)\\n\\ts_memtime %%0\\n\\ts_waitcnt lgkmcnt(0)\" : \"=s\"(grid_ts[%d]) : : \"memory\");" % i)
+
+    if ts_mode:
+        A("unsigned long long grid_ts[10];")
+    TS(0)
+    A("const T Z = static_cast<T>(0);")
+    A("const T *d_L = &grid_model_constants(static_cast<const T *>(nullptr))[%d + %d*lane]; // this lane's table row (gen_branch_frame_constants)" % (tab, RL))
+    A("(void)d_robotModel;")
+    A("T Lc[12]; // link constants: Ic (6, about the centre of mass), c (3), m, damping, axis")
+    A("#pragma unroll")
+    A("for (int r = 0; r < 12; r++) { Lc[r] = d_L[r]; }")
+    A("const int jid = static_cast<int>(d_L[12]); const bool active = jid >= 0; const int js = active ? jid : 0;")
+    A("const int pos = static_cast<int>(d_L[13]), Lb = static_cast<int>(d_L[14]), level = static_cast<int>(d_L[15]), slot = static_cast<int>(d_L[16]);")
+    A("const int cbase = static_cast<int>(d_L[17]), shape = static_cast<int>(d_L[18]), plen = static_cast<int>(d_L[19]), ubase = static_cast<int>(d_L[20]), mstart = static_cast<int>(d_L[21]);")
+    for c in range(maxchild):
+        A("const int cs%d = static_cast<int>(d_L[%d]); // child branch %d of this lane's branch (-1: none)" % (c, H + D + c, c))
+    A("T *s_Mc = &s_X[0], *s_Uc = &s_X[%d + ubase], *s_G = &s_X[%d], *s_trash = &s_X[%d]; // (valid once the frame chain is done with X(q))" % (P["nnz"], 2 * P["nnz"], 2 * P["nnz"] + 28 * P["nb"]))
+    A("const int own = Lb - 1 - pos; // index of this lane's joint on the root path of its branch (tip -> root); -1 on lanes without a joint")
+    A("const int li = jid - cbase;   // index of the joint inside its base-rooted component")
+    A("T *s_Sp = &s_SP[%d*slot]; // joint axes along the root path of this lane's branch, in the branch frame" % (6 * D))
+    A("(void)level; (void)plen; (void)s_G; (void)mstart;")
+    for i in range(D):
+        A("const int pc%d = static_cast<int>(d_L[%d]); const bool pv%d = pc%d >= 0; const int pj%d = pv%d ? (pc%d >> 2) : js; const bool act%d = pv%d && (%d >= own);"
+          % (i, H + i, i, i, i, i, i, i, i, i))
+    A("// zero image of dc/du (unrelated joints, and rows outside the component of a column, stay exactly zero)")
+    A("grid_wave_sync();")
+    A("for (int e = lane; e < %d; e += %d) {" % ((2 * n * n + 3) // 4, lanes), True)
+    A("#pragma unroll")
+    A("for (int r = 0; r < 4; r++) { s_df_du[4*e + r] = Z; }")
+    self.gen_add_end_control_flow()
+    # ------------------------------------------------------------------ frame chain along the root path
+    TS(1)
+    A("//")
+    A("// frames: walk the root path of this lane's branch, tip -> root")
+    A("//")
+    A("T myR[9], myp[3], TR[9], Tp[3], gvec[3] = {Z, Z, Z};")
+    A("{", True)
+    A("T rj[%d][3]; // origins of the path joints' frames in their parents' coordinates: all table reads issued before the first use" % D)
+    for i in range(D - 1):
+        A("{ const T *d_r = &grid_model_constants(static_cast<const T *>(nullptr))[%d + 4*pj%d]; rj[%d][0] = d_r[0]; rj[%d][1] = d_r[1]; rj[%d][2] = d_r[2]; }" % (roff, i, i, i, i))
+    A("T Rc[9] = {static_cast<T>(1), Z, Z, Z, static_cast<T>(1), Z, Z, Z, static_cast<T>(1)};")
+    A("T pc[3] = {Z, Z, Z};")
+    A("#pragma unroll")
+    A("for (int r = 0; r < 9; r++) { myR[r] = Rc[r]; TR[r] = Rc[r]; }")
+    A("#pragma unroll")
+    A("for (int r = 0; r < 3; r++) { myp[r] = pc[r]; Tp[r] = pc[r]; }")
+    junction_steps = sorted(set(len(P["branches"][b]) for b in range(P["nb"]) if P["pb"][b] >= 0))
+    root_steps = sorted(set(len(p_) - 1 for p_ in P["paths"]))
+    for i in range(D):
+        A("{ // path step %d" % i, True)
+        if 0 < i < maxLb:
+            A("#pragma unroll")
+            A("for (int r = 0; r < 9; r++) { myR[r] = (own == %d) ? Rc[r] : myR[r]; }" % i)
+            A("#pragma unroll")
+            A("for (int r = 0; r < 3; r++) { myp[r] = (own == %d) ? pc[r] : myp[r]; }" % i)
+        if i in junction_steps:
+            A("#pragma unroll")
+            A("for (int r = 0; r < 9; r++) { TR[r] = (Lb == %d) ? Rc[r] : TR[r]; } // pose of the parent branch's frame in this branch's frame" % i)
+            A("#pragma unroll")
+            A("for (int r = 0; r < 3; r++) { Tp[r] = (Lb == %d) ? pc[r] : Tp[r]; }" % i)
+        A("if (active && pos == 0) { // joint axis of path joint %d in the branch frame, parked for the walks below (zero beyond the root)" % i, True)
+        A("const int pa = pc%d & 3; T w[3];" % i)
+        A("#pragma unroll")
+        A("for (int r = 0; r < 3; r++) { const T wr = (pa == 0) ? Rc[3*r] : ((pa == 1) ? Rc[3*r + 1] : Rc[3*r + 2]); w[r] = pv%d ? wr : Z; }" % i)
+        A("s_Sp[%d] = w[0]; s_Sp[%d] = w[1]; s_Sp[%d] = w[2];" % (6 * i, 6 * i + 1, 6 * i + 2))
+        A("s_Sp[%d] = pc[1]*w[2] - pc[2]*w[1]; s_Sp[%d] = pc[2]*w[0] - pc[0]*w[2]; s_Sp[%d] = pc[0]*w[1] - pc[1]*w[0];" % (6 * i + 3, 6 * i + 4, 6 * i + 5))
+        self.gen_add_end_control_flow()
+        A("const T *Ei = &s_X[GRID_X_STRIDE*pj%d]; // E(q) of that joint: parent -> child coordinates (row-major)" % i)
+        A("T Rn[9];")
+        A("#pragma unroll")
+        A("for (int r = 0; r < 3; r++) {", True)
+        A("#pragma unroll")
+        A("for (int c = 0; c < 3; c++) { Rn[3*r + c] = Rc[3*r]*Ei[c] + Rc[3*r + 1]*Ei[3 + c] + Rc[3*r + 2]*Ei[6 + c]; }")
+        self.gen_add_end_control_flow()
+        if i in root_steps:
+            A("if (plen == %d) { gvec[0] = gravity*Rn[2]; gvec[1] = gravity*Rn[5]; gvec[2] = gravity*Rn[8]; } // base acceleration (0,0,g) in this branch's coordinates" % (i + 1))
+        if i < D - 1:
+            A("#pragma unroll")
+            A("for (int r = 0; r < 3; r++) { pc[r] -= Rn[3*r]*rj[%d][0] + Rn[3*r + 1]*rj[%d][1] + Rn[3*r + 2]*rj[%d][2]; }" % (i, i, i))
+            A("#pragma unroll")
+            A("for (int r = 0; r < 9; r++) { Rc[r] = Rn[r]; }")
+        self.gen_add_end_control_flow()
+    self.gen_add_end_control_flow()
+    self.gen_add_sync(use_thread_group)
+    # ------------------------------------------------------------------ own link: S, inertia in F_b
+    TS(2)
+    A("//")
+    A("// this lane's link in its branch frame: joint axis, inertia; velocity and bias acceleration by the running sums along the path")
+    A("//")
+    steps = [k for k in (1, 2, 4, 8) if k < maxLb]
+    A("T mkd[GRID_SCAN_STEPS];")
+    if not steps:
+        A("mkd[0] = Z;")
+    for s_, k in enumerate(steps):
+        A("mkd[%d] = (pos + %d < Lb) ? static_cast<T>(1) : Z;" % (s_, k))
+    A("const T qd = active ? s_qd[js] : Z;")
+    A("T S[6];")
+    A("{ const int ax = static_cast<int>(Lc[11]);")
+    A("  #pragma unroll")
+    A("  for (int r = 0; r < 3; r++) { S[r] = (ax == 0) ? myR[3*r] : ((ax == 1) ? myR[3*r+1] : myR[3*r+2]); } }")
+    A("S[3] = myp[1]*S[2] - myp[2]*S[1]; S[4] = myp[2]*S[0] - myp[0]*S[2]; S[5] = myp[0]*S[1] - myp[1]*S[0];")
+    A("T I[10]; // this link's inertia about the origin of its branch frame")
+    A("{", True)
+    A("T d[3], RI[9];")
+    A("#pragma unroll")
+    A("for (int r = 0; r < 3; r++) {", True)
+    A("d[r] = myp[r] + myR[3*r]*Lc[6] + myR[3*r+1]*Lc[7] + myR[3*r+2]*Lc[8]; // centre of mass")
+    A("RI[3*r]   = myR[3*r]*Lc[0] + myR[3*r+1]*Lc[1] + myR[3*r+2]*Lc[2];")
+    A("RI[3*r+1] = myR[3*r]*Lc[1] + myR[3*r+1]*Lc[3] + myR[3*r+2]*Lc[4];")
+    A("RI[3*r+2] = myR[3*r]*Lc[2] + myR[3*r+1]*Lc[4] + myR[3*r+2]*Lc[5];")
+    self.gen_add_end_control_flow()
+    A("const T md0 = Lc[9]*d[0], md1 = Lc[9]*d[1], md2 = Lc[9]*d[2];")
+    for k, (r_, c_) in enumerate(((0, 0), (0, 1), (0, 2), (1, 1), (1, 2), (2, 2))):
+        rot = "RI[%d]*myR[%d] + RI[%d]*myR[%d] + RI[%d]*myR[%d]" % (3 * r_, 3 * c_, 3 * r_ + 1, 3 * c_ + 1, 3 * r_ + 2, 3 * c_ + 2)
+        if r_ == c_:
+            o1, o2 = [x for x in range(3) if x != r_]
+            A("I[%d] = %s + md%d*d[%d] + md%d*d[%d];" % (k, rot, o1, o1, o2, o2))
+        else:
+            A("I[%d] = %s - md%d*d[%d];" % (k, rot, r_, c_))
+    A("I[6] = md0; I[7] = md1; I[8] = md2; I[9] = Lc[9];")
+    self.gen_add_end_control_flow()
+    A("const T damping = Lc[10];")
+
+    def walk_open(with_qdd):
+        """Software-pipelined walk along the root path, root -> tip: the LDS reads of step i-1 are issued before the arithmetic of step i and
+        a scheduling fence closes every step (otherwise the compiler hoists all the loads of the walk to its top and spills)."""
+        A("T Sn[6], qdn%s;" % (", qddn" if with_qdd else ""))
+        walk_fetch(D - 1, with_qdd)
+
+    def walk_fetch(i, with_qdd):
+        A("#pragma unroll")
+        A("for (int r = 0; r < 6; r++) { Sn[r] = s_Sp[%d + r]; }" % (6 * i))
+        A("qdn = act%d ? s_qd[pj%d] : Z;" % (i, i))
+        if with_qdd:
+            A("qddn = act%d ? s_qdd[pj%d] : Z;" % (i, i))
+
+    def walk_step(i, with_qdd):
+        A("{ // path step %d" % i, True)
+        A("T Spi[6]; const T qdi = qdn;%s" % (" const T qddi = qddn;" if with_qdd else ""))
+        A("#pragma unroll")
+        A("for (int r = 0; r < 6; r++) { Spi[r] = Sn[r]; }")
+        if i > 0:
+            walk_fetch(i - 1, with_qdd)
+
+    def walk_close():
+        A("GRID_SCHED_FENCE();")
+        self.gen_add_end_control_flow()
+
+    A("T v[6] = {Z, Z, Z, Z, Z, Z}, a[6] = {Z, Z, Z, Z, Z, Z};")
+    A("{", True)
+    walk_open(False)
+    for i in range(D - 1, -1, -1):
+        walk_step(i, False)
+        A("T Pdi[6];")
+        A("#pragma unroll")
+        A("for (int r = 0; r < 6; r++) { v[r] += Spi[r]*qdi; }")
+        A("grid_mxm(Pdi, v, Spi);")
+        A("#pragma unroll")
+        A("for (int r = 0; r < 6; r++) { a[r] += Pdi[r]*qdi; }")
+        walk_close()
+    self.gen_add_end_control_flow()
+    A("a[3] += gvec[0]; a[4] += gvec[1]; a[5] += gvec[2];")
+    A("T Pd[6]; grid_mxm(Pd, v, S); // = S-dot of the own joint")
+    # body quantities and composites (as _tip_frame_gradient._emit_bias, with a given)
+    TS(3)
+    A("T IC[10], BC[12], fC[6];")
+    A("{", True)
+    A("T Iv[6]; grid_rbi_mul(Iv, I, v); // [n; l]: the link's momentum")
+    A("grid_rbi_mul(fC, I, a); grid_fxv_peq(fC, v, Iv);")
+    A("const T A00 = v[1]*I[2] - v[2]*I[1], A01 = v[1]*I[4] - v[2]*I[3], A02 = v[1]*I[5] - v[2]*I[4];")
+    A("const T A10 = v[2]*I[0] - v[0]*I[2], A11 = v[2]*I[1] - v[0]*I[4], A12 = v[2]*I[2] - v[0]*I[5];")
+    A("const T A20 = v[0]*I[1] - v[1]*I[0], A21 = v[0]*I[3] - v[1]*I[1], A22 = v[0]*I[4] - v[1]*I[2];")
+    A("const T uh = static_cast<T>(2)*(v[3]*I[6] + v[4]*I[7] + v[5]*I[8]);")
+    A("BC[0] = static_cast<T>(2)*(A00 - I[6]*v[3]) + uh;")
+    A("BC[1] = A01 + A10 - I[6]*v[4] - I[7]*v[3];")
+    A("BC[2] = A02 + A20 - I[6]*v[5] - I[8]*v[3];")
+    A("BC[3] = static_cast<T>(2)*(A11 - I[7]*v[4]) + uh;")
+    A("BC[4] = A12 + A21 - I[7]*v[5] - I[8]*v[4];")
+    A("BC[5] = static_cast<T>(2)*(A22 - I[8]*v[5]) + uh;")
+    A("#pragma unroll")
+    A("for (int r = 0; r < 6; r++) { BC[6 + r] = Iv[r]; }")
+    self.gen_add_end_control_flow()
+    A("#pragma unroll")
+    A("for (int r = 0; r < 10; r++) { IC[r] = I[r]; }")
+    A("grid_suffix_sum(IC, mkd); grid_suffix_sum(BC, mkd); grid_suffix_sum(fC, mkd); // composites over the rest of the branch")
+    for lv in range(maxlevel, 0, -1):
+        A("{ // tree level %d -> %d: branch totals re-expressed in the parent branch's frame and handed to all of its lanes" % (lv, lv - 1), True)
+        A("T y[28]; grid_junction_up(y, TR, Tp, IC, BC, fC);")
+        A("if (active && level == %d && pos == 0) {" % lv, True)
+        A("#pragma unroll")
+        A("for (int r = 0; r < 28; r++) { s_G[28*slot + r] = y[r]; }")
+        self.gen_add_end_control_flow()
+        self.gen_add_sync(use_thread_group)
+        for c in range(maxchild):
+            A("{ const int cs = cs%d;" % c)
+            A("  if (level == %d && cs >= 0) {" % (lv - 1), True)
+            A("const T *g = &s_G[28*cs];")
+            A("#pragma unroll")
+            A("for (int r = 0; r < 10; r++) { IC[r] += g[r]; }")
+            A("#pragma unroll")
+            A("for (int r = 0; r < 12; r++) { BC[r] += g[10 + r]; }")
+            A("#pragma unroll")
+            A("for (int r = 0; r < 6; r++) { fC[r] += g[22 + r]; }")
+            self.gen_add_end_control_flow()
+            A("}")
+        self.gen_add_end_control_flow()
+    # ------------------------------------------------------------------ pass 1
+    TS(4)
+    A("// everything that does not depend on qdd: t1, t2, t4, tau - c; then the entries that couple this joint with its ancestors")
+    A("T t1[6], t4[3];")
+    A("grid_rbi_mul(t1, IC, S);")
+    A("grid_btmul(t4, BC, S);")
+    A("if (active) { s_qdd[jid] = s_u[jid] - (grid_dot6(S, fC) + damping*qd); }")
+    A("{", True)
+    A("T t2[6]; grid_bmul(t2, BC, S); grid_rbi_mul_peq(t2, IC, Pd, static_cast<T>(2));")
+    A("T vr[6] = {Z, Z, Z, Z, Z, Z};")
+    walk_open(False)
+    for i in range(D - 1, -1, -1):
+        walk_step(i, False)
+        A("T Pdi[6];")
+        A("#pragma unroll")
+        A("for (int r = 0; r < 6; r++) { vr[r] += Spi[r]*qdi; }")
+        A("grid_mxm(Pdi, vr, Spi);")
+        A("const T mkj = grid_dot6(Spi, t1), up_d = grid_dot6(Spi, t2);")
+        A("const T lo_d = static_cast<T>(2)*grid_dot6(t1, Pdi) + t4[0]*Spi[0] + t4[1]*Spi[1] + t4[2]*Spi[2];")
+        A("// (branch-free: lanes that have no such entry write to a spare word)")
+        A("*(act%d ? &s_Mc[mstart + plen - %d] : s_trash) = mkj; // (ancestors in ascending order, then the diagonal)" % (i, i + 1))
+        A("*(act%d ? &s_df_du[(%d + jid)*%d + pj%d] : s_trash) = up_d + ((own == %d) ? damping : Z); // + damping on the diagonal (oracle _test.py:486)" % (i, n, n, i, i))
+        A("*((act%d && own != %d) ? &s_df_du[(%d + pj%d)*%d + jid] : s_trash) = lo_d;" % (i, i, n, i, n))
+        walk_close()
+    self.gen_add_end_control_flow()
+    self.gen_add_sync(use_thread_group)
+    # ------------------------------------------------------------------ factorisation per component shape
+    TS(5)
+    shapes = P["shapes"]
+    NCmax = max(len(s_) for s_ in shapes)
+    ancs = [_anc_local(s_) for s_ in shapes]
+    A("// tree-sparse U D U^T of the joint-space inertia of this lane's component (leaves first: no fill-in), wave-uniform inside the component,")
+    A("// fused with the forward substitution of tau - c; the first lane of the component parks the factors in the (now free) X(q) storage")
+    A("T bq[%d];" % NCmax)
+    for si, sig in enumerate(shapes):
+        Nc = len(sig)
+        an = ancs[si]
+        midx = {}
+        for k in range(Nc):
+            for i in an[k] + [k]:
+                midx[(i, k)] = len(midx)
+        A("%sif (shape == %d) { // component of %d joints" % ("" if si == 0 else "else ", si, Nc), True)
+        for k in range(Nc):
+            A(" ".join("T A%d_%d = s_Mc[ubase + %d];" % (i, k, midx[(i, k)]) for i in an[k] + [k]))
+        A("#pragma unroll")
+        A("for (int i = 0; i < %d; i++) { bq[i] = s_qdd[cbase + i]; }" % Nc)
+        for k in range(Nc - 1, -1, -1):
+            A("const T rd%d = grid_rcp(A%d_%d);" % (k, k, k))
+            if an[k]:
+                A(" ".join("const T U%d_%d = A%d_%d*rd%d;" % (i, k, i, k, k) for i in an[k]))
+                for j in an[k]:
+                    A(" ".join("A%d_%d -= U%d_%d*A%d_%d;" % (i, j, i, k, j, k) for i in an[k] if i <= j))
+                A(" ".join("bq[%d] -= U%d_%d*bq[%d];" % (i, i, k, k) for i in an[k]))
+            A("bq[%d] *= rd%d;" % (k, k))
+        for k in range(1, Nc):
+            if an[k]:
+                A("bq[%d] -= %s;" % (k, " + ".join("U%d_%d*bq[%d]" % (i, k, i) for i in an[k])))
+        A("if (li == 0) { // the first lane of the component parks the factors and qdd", True)
+        for k in range(Nc):
+            A(" ".join(["s_Uc[%d] = U%d_%d;" % (midx[(i, k)], i, k) for i in an[k]] + ["s_Uc[%d] = rd%d;" % (midx[(k, k)], k)]))
+        self.gen_add_end_control_flow()
+        self.gen_add_end_control_flow()
+    self.gen_add_sync(use_thread_group)  # every lane has read tau - c
+    for si, sig in enumerate(shapes):
+        A("%sif (shape == %d && li == 0) {" % ("" if si == 0 else "else ", si), True)
+        A("#pragma unroll")
+        A("for (int i = 0; i < %d; i++) { s_qdd[cbase + i] = bq[i]; }" % len(sig))
+        self.gen_add_end_control_flow()
+    self.gen_add_sync(use_thread_group)
+    # ------------------------------------------------------------------ pass 2
+    TS(6)
+    A("// the acceleration-dependent parts: a += sum over the ancestors of S_i qdd_i, f^C += sum over the subtree of I_k da_k")
+    A("{", True)
+    A("T da[6] = {Z, Z, Z, Z, Z, Z}, Ida[6];")
+    A("{", True)
+    walk_open(True)
+    for i in range(D - 1, -1, -1):
+        walk_step(i, True)
+        A("#pragma unroll")
+        A("for (int r = 0; r < 6; r++) { da[r] += Spi[r]*qddi; }")
+        A("(void)qdi;")
+        walk_close()
+    self.gen_add_end_control_flow()
+    A("grid_rbi_mul(Ida, I, da); grid_suffix_sum(Ida, mkd);")
+    for lv in range(maxlevel, 0, -1):
+        A("{ // tree level %d -> %d" % (lv, lv - 1), True)
+        A("T y[6]; grid_force_up(y, TR, Tp, Ida);")
+        A("if (active && level == %d && pos == 0) {" % lv, True)
+        A("#pragma unroll")
+        A("for (int r = 0; r < 6; r++) { s_G[28*slot + r] = y[r]; }")
+        self.gen_add_end_control_flow()
+        self.gen_add_sync(use_thread_group)
+        for c in range(maxchild):
+            A("{ const int cs = cs%d;" % c)
+            A("  if (level == %d && cs >= 0) {" % (lv - 1), True)
+            A("#pragma unroll")
+            A("for (int r = 0; r < 6; r++) { Ida[r] += s_G[28*cs + r]; }")
+            self.gen_add_end_control_flow()
+            A("}")
+        self.gen_add_end_control_flow()
+    A("#pragma unroll")
+    A("for (int r = 0; r < 6; r++) { a[r] += da[r]; fC[r] += Ida[r]; }")
+    self.gen_add_end_control_flow()
+    A("{", True)
+    A("T Pdd[6]; grid_mxm(Pdd, a, S); grid_mxm_peq(Pdd, v, Pd);")
+    A("T t3[6]; grid_bmul(t3, BC, Pd); grid_rbi_mul_peq(t3, IC, Pdd, static_cast<T>(1)); grid_fxv_peq(t3, S, fC);")
+    A("T vr[6] = {Z, Z, Z, Z, Z, Z}, ar[6] = {Z, Z, Z, gvec[0], gvec[1], gvec[2]};")
+    walk_open(True)
+    for i in range(D - 1, -1, -1):
+        walk_step(i, True)
+        A("T Pdi[6], Pddi[6];")
+        A("#pragma unroll")
+        A("for (int r = 0; r < 6; r++) { vr[r] += Spi[r]*qdi; }")
+        A("grid_mxm(Pdi, vr, Spi);")
+        A("#pragma unroll")
+        A("for (int r = 0; r < 6; r++) { ar[r] += Pdi[r]*qdi + Spi[r]*qddi; }")
+        A("grid_mxm(Pddi, ar, Spi); grid_mxm_peq(Pddi, vr, Pdi);")
+        A("const T up_q = grid_dot6(Spi, t3), lo_q = grid_dot6(t1, Pddi) + t4[0]*Pdi[0] + t4[1]*Pdi[1] + t4[2]*Pdi[2];")
+        A("*(act%d ? &s_df_du[jid*%d + pj%d] : s_trash) = up_q;" % (i, n, i))
+        A("*((act%d && own != %d) ? &s_df_du[pj%d*%d + jid] : s_trash) = lo_q;" % (i, i, i, n))
+        walk_close()
+    self.gen_add_end_control_flow()
+    self.gen_add_sync(use_thread_group)
+    # ------------------------------------------------------------------ column solves
+    TS(7)
+    A("// df/du = -M^-1 dc/du for the two columns this lane owns (rows of its component; all other rows of the column are zero)")
+    for si, sig in enumerate(shapes):
+        Nc = len(sig)
+        an = ancs[si]
+        midx = {}
+        for k in range(Nc):
+            for i in an[k] + [k]:
+                midx[(i, k)] = len(midx)
+        A("%sif (shape == %d) {" % ("" if si == 0 else "else ", si), True)
+        A("T x[%d], y[%d];" % (Nc, Nc))
+        A("#pragma unroll")
+        A("for (int i = 0; i < %d; i++) { x[i] = s_df_du[jid*%d + cbase + i]; y[i] = s_df_du[(%d + jid)*%d + cbase + i]; }" % (Nc, n, n, n))
+        for k in range(Nc - 1, 0, -1):
+            for i in an[k]:
+                A("{ const T uu = s_Uc[%d]; x[%d] -= uu*x[%d]; y[%d] -= uu*y[%d]; }" % (midx[(i, k)], i, k, i, k))
+        for k in range(Nc):
+            A("{ const T rr = s_Uc[%d]; x[%d] *= rr; y[%d] *= rr; }" % (midx[(k, k)], k, k))
+        for k in range(1, Nc):
+            for i in an[k]:
+                A("{ const T uu = s_Uc[%d]; x[%d] -= uu*x[%d]; y[%d] -= uu*y[%d]; }" % (midx[(i, k)], k, i, k, i))
+        A("#pragma unroll")
+        A("for (int i = 0; i < %d; i++) { s_df_du[jid*%d + cbase + i] = -x[i]; s_df_du[(%d + jid)*%d + cbase + i] = -y[i]; }" % (Nc, n, n, n))
+        self.gen_add_end_control_flow()
+    if ts_mode:
+        self.gen_add_sync(use_thread_group)
+        TS(8)
+        A("if (lane == 0) { for (int i = 1; i < 9; i++) { s_df_du[i] = static_cast<T>(static_cast<float>(grid_ts[i] - grid_ts[0])); } s_df_du[0] = Z; }")
+    self.gen_add_end_function()
+
+
+def gen_forward_dynamics_gradient_inner_branch_function_call(self, use_thread_group=False, s_df_du_name="s_df_du"):
+    self.gen_add_code_line("forward_dynamics_gradient_inner_branch<T>(%s, s_qd, s_u, s_X, s_SP, s_qdd, d_robotModel, gravity, lane);" % s_df_du_name)

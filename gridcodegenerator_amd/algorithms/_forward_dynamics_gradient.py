@@ -33,6 +33,9 @@ def gen_forward_dynamics_gradient_inner_python(self, use_thread_group=False, use
     if self.tip_frame and stop in (0, 5, 6, 7, 20):  # serial revolute chains: everything after the X update is one fused inner in the tip link's frame
         self.gen_forward_dynamics_gradient_inner_tip_function_call(use_thread_group, use_qdd_Minv_input, s_df_du_name)
         return
+    if getattr(self, "branch_frame", False) and stop in (0, 20) and not use_qdd_Minv_input:  # trees of revolute joints: one fused inner, every branch in its tip link's frame
+        self.gen_forward_dynamics_gradient_inner_branch_function_call(use_thread_group, s_df_du_name)
+        return
     if stop == 1:
         self.gen_add_code_line("if (lane < %d) { %s[lane] = s_X[GRID_X_STRIDE*lane]; }" % (n, s_df_du_name))
         return
@@ -76,10 +79,15 @@ def gen_forward_dynamics_gradient_device(self, use_thread_group=False, use_qdd_M
     self.gen_add_code_line("template <typename T>")
     self.gen_add_code_line("__device__ __forceinline__")
     self.gen_add_code_line(func_def, True)
-    self.gen_add_code_line("T *s_X = &s_work[GRID_OFF_X]; T *s_U = &s_work[GRID_OFF_U]; T *s_T = &s_work[GRID_OFF_T]; T *s_F = &s_work[GRID_OFF_F]; T *s_J = &s_work[GRID_OFF_J];")
-    if not use_qdd_Minv_input:
-        self.gen_add_code_line("T *s_Minv = &s_work[GRID_OFF_MINV]; T *s_qdd = &s_work[GRID_OFF_QDD];")
-    self.gen_add_code_line("(void)s_U; (void)s_T;")
+    branch = getattr(self, "branch_frame", False) and not use_qdd_Minv_input
+    if branch:
+        self.gen_add_code_line("// (this path only touches the first FD_DU_LDS_PER_SOLVE elements of s_work)")
+        self.gen_add_code_line("T *s_X = &s_work[GRID_OFF_X]; T *s_SP = &s_work[FD_DU_OFF_SP]; T *s_qdd = &s_work[FD_DU_OFF_QDD];")
+    else:
+        self.gen_add_code_line("T *s_X = &s_work[GRID_OFF_X]; T *s_U = &s_work[GRID_OFF_U]; T *s_T = &s_work[GRID_OFF_T]; T *s_F = &s_work[GRID_OFF_F]; T *s_J = &s_work[GRID_OFF_J];")
+        if not use_qdd_Minv_input:
+            self.gen_add_code_line("T *s_Minv = &s_work[GRID_OFF_MINV]; T *s_qdd = &s_work[GRID_OFF_QDD];")
+        self.gen_add_code_line("(void)s_U; (void)s_T;")
     self.gen_load_update_XImats_helpers_function_call(use_thread_group)
     self.gen_forward_dynamics_gradient_inner_python(use_thread_group, use_qdd_Minv_input)
     self.gen_add_sync(use_thread_group)
@@ -110,15 +118,18 @@ def gen_forward_dynamics_gradient_kernel(self, use_thread_group=False, use_qdd_M
     self.gen_add_code_line("template <typename T>")
     self.gen_add_code_line("__global__ GRID_LAUNCH_BOUNDS")
     self.gen_add_code_line(func_def, True)
-    self.gen_kernel_prologue("GRID_LDS_PER_SOLVE")
+    self.gen_kernel_prologue("GRID_LDS_PER_SOLVE" if use_qdd_Minv_input else "FD_DU_LDS_PER_SOLVE")
     import os
     if os.environ.get("GRID_DEBUG_STOP", "0") == "9":  # timing ablation only: an empty kernel (launch + dispatch cost)
         self.gen_add_code_line("if (NUM_TIMESTEPS > -1) {return;}")
     if use_qdd_Minv_input:
         self.gen_add_code_line("T *s_q_qd = &s_mem[GRID_OFF_IN]; T *s_q = s_q_qd; T *s_qd = &s_q_qd[%d]; T *s_qdd = &s_mem[GRID_OFF_QDD];" % n)
     else:
-        self.gen_add_code_line("T *s_q_qd_u = &s_mem[GRID_OFF_IN]; T *s_q = s_q_qd_u; T *s_qd = &s_q_qd_u[%d]; T *s_u = &s_q_qd_u[%d]; T *s_qdd = &s_mem[GRID_OFF_QDD];" % (n, 2 * n))
-    self.gen_add_code_line("T *s_Minv = &s_mem[GRID_OFF_MINV]; T *s_df_du = &s_out_all[grp*%d]; (void)s_Minv; (void)s_qdd;" % (2 * n * n))
+        self.gen_add_code_line("T *s_q_qd_u = &s_mem[GRID_OFF_IN]; T *s_q = s_q_qd_u; T *s_qd = &s_q_qd_u[%d]; T *s_u = &s_q_qd_u[%d]; T *s_qdd = &s_mem[%s];" % (n, 2 * n, "FD_DU_OFF_QDD" if getattr(self, "branch_frame", False) else "GRID_OFF_QDD"))
+    if getattr(self, "branch_frame", False) and not use_qdd_Minv_input:
+        self.gen_add_code_line("T *s_df_du = &s_out_all[grp*%d]; (void)s_qdd;" % (2 * n * n))
+    else:
+        self.gen_add_code_line("T *s_Minv = &s_mem[GRID_OFF_MINV]; T *s_df_du = &s_out_all[grp*%d]; (void)s_Minv; (void)s_qdd;" % (2 * n * n))
     if single_call_timing:
         self.gen_add_code_line("const int k = 0; const int kc = 0; const bool valid = (blockIdx.x + blockIdx.y == 0) && (grp == 0); const int lane = lane_id; const int NUM_TIMESTEPS_OUT = 1;")
         self.gen_add_code_line("if (!valid) {return;}")
@@ -179,7 +190,7 @@ def gen_forward_dynamics_gradient_host(self, mode=0):
     if single_call_timing:
         self.gen_add_code_line("struct timespec start, end; clock_gettime(CLOCK_MONOTONIC,&start);")
     self.gen_add_code_lines(["if (USE_QDD_MINV_FLAG) {hipLaunchKernelGGL((" + kern + "),block_dimms,thread_dimms,FD_DU_DYNAMIC_SHARED_MEM_COUNT*sizeof(T),0,hd_data->d_df_du,hd_data->d_q_qd_u,stride_q_qd,hd_data->d_qdd,hd_data->d_Minv,d_robotModel,gravity,num_timesteps);}",
-                             "else {hipLaunchKernelGGL((" + kern + "),block_dimms,thread_dimms,FD_DU_DYNAMIC_SHARED_MEM_COUNT*sizeof(T),0,hd_data->d_df_du,hd_data->d_q_qd_u,stride_q_qd,d_robotModel,gravity,num_timesteps);}",
+                             "else {hipLaunchKernelGGL((" + kern + "),block_dimms,thread_dimms,GRID_MAX_SOLVES_PER_BLOCK*(FD_DU_LDS_PER_SOLVE + GRID_OUT_PER_SOLVE)*sizeof(T),0,hd_data->d_df_du,hd_data->d_q_qd_u,stride_q_qd,d_robotModel,gravity,num_timesteps);}",
                              "gpuErrchk(hipGetLastError()); gpuErrchk(hipDeviceSynchronize());"])
     if single_call_timing:
         self.gen_add_code_line("clock_gettime(CLOCK_MONOTONIC,&end);")

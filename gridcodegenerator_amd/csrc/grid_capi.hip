@@ -106,9 +106,14 @@ int grid_forward_dynamics_gradient_device(grid_handle *h, const float *d_q_qd_u,
     int rc = check_args(h, num_timesteps);
     if (rc) return rc;
     if (num_timesteps == 0) return 0;
-    dim3 grid, block;
-    launch_dims(h, num_timesteps, &grid, &block);
-    hipLaunchKernelGGL((grid::forward_dynamics_gradient_kernel<float>), grid, block, lds_bytes(h),
+    // this kernel has its own (smaller) LDS slice and suggested block size: FD_DU_LDS_PER_SOLVE, FD_DU_SUGGESTED_THREADS
+    int threads = h->threads > 0 ? h->threads : grid::FD_DU_SUGGESTED_THREADS;
+    int gpb = threads / grid::GRID_LANES_PER_SOLVE;
+    if (gpb > grid::GRID_MAX_SOLVES_PER_BLOCK) gpb = grid::GRID_MAX_SOLVES_PER_BLOCK;
+    if (gpb < 1) gpb = 1;
+    int blocks = h->blocks > 0 ? h->blocks : (num_timesteps + gpb - 1) / gpb;
+    const dim3 grid(blocks < 1 ? 1 : blocks, 1, 1), block(threads, 1, 1);
+    hipLaunchKernelGGL((grid::forward_dynamics_gradient_kernel<float>), grid, block, (size_t)gpb * (grid::FD_DU_LDS_PER_SOLVE + grid::GRID_OUT_PER_SOLVE) * sizeof(float),
                        (hipStream_t)stream, d_df_du, d_q_qd_u, stride_q_qd_u, h->d_robotModel, gravity, num_timesteps);
     GRID_TRY(hipGetLastError());
     return 0;

@@ -53,6 +53,12 @@ __device__ __forceinline__ double grid_rcp(const double x) { return 1.0/x; }
 
 // X is stored compactly per joint: X[0..8] = E (row-major 3x3, top-left == bottom-right block),
 // X[9..17] = B (bottom-left block); the top-right block is identically zero.
+// scheduling fence: nothing is moved across it by the instruction scheduler (keeps software-pipelined loops from being re-clustered)
+#if defined(__HIP_DEVICE_COMPILE__)
+#define GRID_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+#else
+#define GRID_SCHED_FENCE() do {} while (0)
+#endif
 #define GRID_X_STRIDE 20  // floats per joint in LDS (18 used; keeps every joint 16-byte aligned)
 
 template <typename T>

@@ -41,6 +41,19 @@ def gen_lds_layout(self):
     if (cur // 4) % 2 == 0:
         cur += 4
     off["TOTAL"] = cur
+    # the forward-dynamics-gradient kernel (u input) of branch-frame robots needs much less: IN | X | path axes | qdd  (M, its factors and the
+    # branch hand-over records re-use the X(q) storage); fewer bytes per solve = more resident waves
+    off["FD_SP"] = off["FD_QDD"] = 0
+    off["FD_TOTAL"] = cur
+    if getattr(self, "branch_frame", False):
+        off["FD_SP"] = off["U"]
+        off["FD_QDD"] = off["FD_SP"] + _pad4(6 * self.branch_plan["D"] * self.branch_plan["nb"])
+        tot = off["FD_QDD"] + _pad4(n)
+        if (tot // 4) % 2 == 0:
+            tot += 4
+        if tot > cur:
+            off["TOTAL"] = cur = tot + (4 if ((tot // 4) % 2 == 0) else 0)
+        off["FD_TOTAL"] = tot
     off["OUT_PER_SOLVE"] = _pad4(2 * n * n)  # output staging, kept behind all slices (contiguous across the lane groups of a wave)
     return off
 
@@ -69,6 +82,8 @@ def gen_model_constant_table(self):
         vals += [m.I[i][row, col] for col in range(6) for row in range(6)]
     if getattr(self, "tip_frame", False):  # one 12-float row of link constants per lane of the lane group (tip-frame gradient path)
         vals += self.gen_tip_frame_link_constants()
+    elif getattr(self, "branch_frame", False):  # per-lane rows of the branch-frame gradient path
+        vals += self.gen_branch_frame_constants()
     for ctype, sfx in (("float", "f"), ("double", "")):
         self.gen_add_code_line("__device__ const %s grid_model_constants_%s[%d] = {" % (ctype, ctype, len(vals)), True)
         for k in range(0, len(vals), 6):

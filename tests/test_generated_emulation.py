@@ -63,10 +63,13 @@ def test_emulated_one_column_per_lane_variant(name, golden):
 
 @pytest.mark.parametrize("name,env", [("iiwa14", {"GRID_GRADIENT_WALK": "lds"}), ("hyq", {"GRID_GRADIENT_WALK": "lds"}), ("atlas", {"GRID_GRADIENT_WALK": "lds"}),
                                       ("iiwa14", {"GRID_REUSE_RNEA": "1"}), ("iiwa14", {"GRID_FUSE_FD": "0"}),
-                                      ("iiwa14", {"GRID_GRADIENT_WALK": "registers"}), ("iiwa14", {"GRID_TIP_CHAIN": "lds"}), ("arm6", {"GRID_GRADIENT_WALK": "registers"})])
+                                      ("iiwa14", {"GRID_GRADIENT_WALK": "registers"}), ("iiwa14", {"GRID_TIP_CHAIN": "lds"}), ("arm6", {"GRID_GRADIENT_WALK": "registers"}),
+                                      ("iiwa14", {"GRID_GRADIENT_WALK": "branch"}), ("hyq", {"GRID_GRADIENT_WALK": "branch"}), ("chain12", {"GRID_GRADIENT_WALK": "branch"}),
+                                      ("atlas", {"GRID_GRADIENT_WALK": "registers"})])
 def test_emulated_generation_variants(name, env, golden):
     """The non-default generated forms stay correct: LDS-assisted forward accumulation of the derivative walk (what deep trees get),
-    RNEA re-use, unfused forward dynamics."""
+    RNEA re-use, unfused forward dynamics; the branch-frame path (default for branched revolute robots such as atlas) forced onto chains and
+    forests (one branch / equal branches, 8- and 16-lane groups), and the column walk forced onto atlas."""
     g = golden(name)
     lib = emu_library(name, max_timesteps=64, env=env)
     n = lib.n

@@ -1,18 +1,27 @@
 #!/usr/bin/env python3
 """Reads the per-wave cycle stamps a GRID_DEBUG_STOP=20 build of the tip-frame kernel leaves in the first outputs of every solve.
-usage: python tools/phase_stamps.py <build-dir> [batch]"""
+usage: python tools/phase_stamps.py <build-dir> [batch] [robot]   (robot other than iiwa14: the branch-frame kernel's 8 stamps)"""
 import sys
 sys.path.insert(0, ".")
 import numpy as np, torch
 from gridcodegenerator_amd.runtime import load
 bdir = sys.argv[1]; N = int(sys.argv[2]) if len(sys.argv) > 2 else 16384
-lib = load("iiwa14", max_timesteps=N, build_dir=bdir)
-rng = np.random.default_rng(0); n = 7
+robot = sys.argv[3] if len(sys.argv) > 3 else "iiwa14"
+lib = load(robot, max_timesteps=N, build_dir=bdir)
+rng = np.random.default_rng(0); n = lib.n
 x = np.hstack([rng.uniform(-np.pi, np.pi, (N, n)), rng.uniform(-2, 2, (N, n)), rng.uniform(-10, 10, (N, n))]).astype(np.float32)
-d_in = torch.from_numpy(x).cuda(); d_out = torch.empty((N, 98), dtype=torch.float32, device="cuda")
+d_in = torch.from_numpy(x).cuda(); d_out = torch.empty((N, 2 * n * n), dtype=torch.float32, device="cuda")
 st = torch.cuda.current_stream().cuda_stream
 for _ in range(20): lib.forward_dynamics_gradient_device(d_in, N, d_out, stream=st)
 torch.cuda.synchronize()
+if robot != "iiwa14":
+    o = d_out.cpu().numpy()[::64 // lib.lanes_per_solve]
+    names = ["table row, zero fill", "frame chain + sync", "link set-up, v, a (walk)", "body, scans, branch hand-over", "pass 1 (M, dc/dqd) + sync", "factorisation, qdd + syncs", "pass 2 (da, f^C, dc/dq) + sync", "column solves"]
+    ph = np.diff(o[:, 0:9], axis=1)
+    print("%s: waves %d; cycles per phase (mean / min / max over waves), total inner %.0f cycles mean" % (robot, o.shape[0], o[:, 8].mean()))
+    for i, nm in enumerate(names):
+        print("  %-45s %7.0f %7.0f %7.0f" % (nm, ph[:, i].mean(), ph[:, i].min(), ph[:, i].max()))
+    sys.exit(0)
 o = d_out.cpu().numpy()[::8]  # one row per wave (8 solves of a wave share their stamps)
 names = ["chain (+link constants)", "link set-up, bias, scans, record + sync", "pass 1, M write + sync", "M read, factorisation, qdd", "qdd-dependent part, pass 2, two solves", "output staging + sync"]
 ph = np.diff(o[:, 0:7], axis=1)
