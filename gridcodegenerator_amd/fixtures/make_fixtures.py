@@ -7,6 +7,7 @@ No URDF files ship with the reference and URDFParser is not in the build contain
               iiwa14.urdf (UNVERIFIED - parity is defined against the
               oracle on this same fixture, throughput depends on the topology only)
   * hyq     - 12-DoF quadruped-like tree (4 legs x [HAA about x, HFE about y, KFE about y]), synthetic
+  * tree12  - 12-DoF tree with nested branching and a second base-rooted component, synthetic
   * atlas   - 30-DoF humanoid-like tree (back 3, neck 1, arms 2x7, legs 2x6), mixed axes, synthetic
   * mixed5  - 5-DoF branched robot with prismatic joints (edge cases for joint models)
   * arm6    - 6-DoF serial chain, revolute joints about mixed axes, oblique joint frames, full inertia tensors (synthetic)
@@ -155,8 +156,41 @@ def chain8():
     return chain12(8, 20261005, "chain8")
 
 
+def tree12():
+    """12-DoF tree with nested branching (trunk 2 -> forearm 2 -> two fingers 2 + 1, and a 3-joint side arm) plus a separate 2-joint tail on the
+    base: three tree levels, two base-rooted components of different shape.  Synthetic; exercises the branch-frame path's level loop."""
+    rng = np.random.default_rng(20261006)
+    joints = []
+
+    def add(name, parent_link, mass, scale):
+        axis = "xyz"[int(rng.integers(0, 3))]
+        com = np.round(rng.uniform(-0.5, 0.5, 3) * scale, 4)
+        d = np.round(mass * (scale ** 2) * rng.uniform(0.05, 0.25, 3), 5)
+        off = np.round(0.1 * float(d.min()) * rng.uniform(-1, 1, 3), 6)
+        xyz = np.round(rng.uniform(-0.3, 0.3, 3), 3)
+        rpy = np.round(rng.uniform(-0.5, 0.5, 3), 3)
+        joints.append(dict(name=name, type="revolute", axis=axis, parent_link=parent_link, xyz=xyz.tolist(), rpy=rpy.tolist(),
+                           damping=[0.0, 0.2, 0.05][len(joints) % 3], limits=[-3.0, 3.0],
+                           link=link(name + "_link", mass, com.tolist(), d.tolist(), off.tolist())))
+        return name + "_link"
+
+    t = add("trunk0", "base", 8.0, 0.3)
+    t = add("trunk1", t, 5.0, 0.3)
+    f = add("fore0", t, 3.0, 0.2)
+    f = add("fore1", f, 2.0, 0.2)
+    a = add("fingerA0", f, 0.4, 0.08)
+    add("fingerA1", a, 0.2, 0.06)
+    add("fingerB0", f, 0.3, 0.08)
+    s_ = add("side0", t, 2.5, 0.2)
+    s_ = add("side1", s_, 1.5, 0.15)
+    add("side2", s_, 0.8, 0.1)
+    g = add("tail0", "base", 1.2, 0.15)
+    add("tail1", g, 0.6, 0.1)
+    return dict(name="tree12", base_link="base", joints=joints)
+
+
 if __name__ == "__main__":
-    for fn in (iiwa14, hyq, atlas, mixed5, arm6, chain12, chain8):
+    for fn in (iiwa14, hyq, atlas, mixed5, arm6, chain12, chain8, tree12):
         d = fn()
         with open(os.path.join(HERE, d["name"] + ".json"), "w") as f:
             json.dump(d, f, indent=1)

@@ -33,6 +33,7 @@ CASES = [  # (golden name, fixture, number of states, zero the damping?)
     ("arm6", "arm6", 8, False),
     ("chain12", "chain12", 8, False),
     ("chain8", "chain8", 8, False),
+    ("tree12", "tree12", 8, False),
 ]
 
 

@@ -29,7 +29,7 @@ def libs():
     return get
 
 
-@pytest.mark.parametrize("name", ["iiwa14", "hyq", "atlas", "mixed5", "arm6", "chain12", "chain8"])
+@pytest.mark.parametrize("name", ["iiwa14", "hyq", "atlas", "mixed5", "arm6", "chain12", "chain8", "tree12"])
 def test_emulated_fd_grad_matches_goldens(name, libs, golden):
     g = golden(name)
     lib = libs(name)
@@ -112,7 +112,7 @@ def test_emulated_empty_batch_is_a_noop(libs):
     assert out.shape == (0, 98)
 
 
-@pytest.mark.parametrize("name", ["iiwa14", "hyq", "atlas", "mixed5", "arm6", "chain12", "chain8"])
+@pytest.mark.parametrize("name", ["iiwa14", "hyq", "atlas", "mixed5", "arm6", "chain12", "chain8", "tree12"])
 def test_emulated_component_kernels(name, libs, golden):
     g = golden(name)
     lib = libs(name)

@@ -8,7 +8,7 @@ import pytest
 from gridcodegenerator_amd.robot import RobotModel
 from oracle.rbd_oracle import Oracle
 
-CASES = ["iiwa14", "iiwa14_nodamp", "hyq", "atlas", "mixed5", "arm6", "chain12", "chain8"]
+CASES = ["iiwa14", "iiwa14_nodamp", "hyq", "atlas", "mixed5", "arm6", "chain12", "chain8", "tree12"]
 
 
 def robot_for(case):
