@@ -265,7 +265,7 @@ def gen_forward_dynamics_gradient_inner_branch(self, use_thread_group=False):
                            "s_qd is the vector of joint velocities in LDS", "s_u is the vector of joint input torques in LDS",
                            "s_X is this solve's compact X(q) storage (the rotation blocks are read; once the frames are known it is re-used for the",
                            "     tree-sparse M, its factors and the branch hand-over records)",
-                           "s_SP is LDS scratch for the joint axes along the root path of every branch (6 values per path joint)",
+                           "s_SP is LDS scratch for the joint axes along the root path of every branch (6 values per path joint, plus one spare record per solve)",
                            "s_qdd is LDS scratch for tau - c and then the joint accelerations",
                            "d_robotModel is the pointer to the initialized model specific helpers on the GPU", "gravity is the gravity constant",
                            "lane is the caller's lane index inside the solve's lane group"], None)
@@ -325,8 +325,18 @@ def gen_forward_dynamics_gradient_inner_branch(self, use_thread_group=False):
     A("for (int r = 0; r < 3; r++) { myp[r] = pc[r]; Tp[r] = pc[r]; }")
     junction_steps = sorted(set(len(P["branches"][b]) for b in range(P["nb"]) if P["pb"][b] >= 0))
     root_steps = sorted(set(len(p_) - 1 for p_ in P["paths"]))
+    A("T En[9]; // E(q) of the next path joint (parent -> child coordinates, row-major): read one step ahead")
+    A("#pragma unroll")
+    A("for (int r = 0; r < 9; r++) { En[r] = s_X[GRID_X_STRIDE*pj0 + r]; }")
+    A("T *s_sp_dst = (active && pos == 0) ? s_Sp : &s_SP[%d]; // the first lane of every branch parks the joint axes of the path; the others write to a spare record" % (6 * D * P["nb"]))
     for i in range(D):
         A("{ // path step %d" % i, True)
+        A("T Ei[9];")
+        A("#pragma unroll")
+        A("for (int r = 0; r < 9; r++) { Ei[r] = En[r]; }")
+        if i < D - 1:
+            A("#pragma unroll")
+            A("for (int r = 0; r < 9; r++) { En[r] = s_X[GRID_X_STRIDE*pj%d + r]; }" % (i + 1))
         if 0 < i < maxLb:
             A("#pragma unroll")
             A("for (int r = 0; r < 9; r++) { myR[r] = (own == %d) ? Rc[r] : myR[r]; }" % i)
@@ -337,14 +347,12 @@ def gen_forward_dynamics_gradient_inner_branch(self, use_thread_group=False):
             A("for (int r = 0; r < 9; r++) { TR[r] = (Lb == %d) ? Rc[r] : TR[r]; } // pose of the parent branch's frame in this branch's frame" % i)
             A("#pragma unroll")
             A("for (int r = 0; r < 3; r++) { Tp[r] = (Lb == %d) ? pc[r] : Tp[r]; }" % i)
-        A("if (active && pos == 0) { // joint axis of path joint %d in the branch frame, parked for the walks below (zero beyond the root)" % i, True)
-        A("const int pa = pc%d & 3; T w[3];" % i)
-        A("#pragma unroll")
-        A("for (int r = 0; r < 3; r++) { const T wr = (pa == 0) ? Rc[3*r] : ((pa == 1) ? Rc[3*r + 1] : Rc[3*r + 2]); w[r] = pv%d ? wr : Z; }" % i)
-        A("s_Sp[%d] = w[0]; s_Sp[%d] = w[1]; s_Sp[%d] = w[2];" % (6 * i, 6 * i + 1, 6 * i + 2))
-        A("s_Sp[%d] = pc[1]*w[2] - pc[2]*w[1]; s_Sp[%d] = pc[2]*w[0] - pc[0]*w[2]; s_Sp[%d] = pc[0]*w[1] - pc[1]*w[0];" % (6 * i + 3, 6 * i + 4, 6 * i + 5))
-        self.gen_add_end_control_flow()
-        A("const T *Ei = &s_X[GRID_X_STRIDE*pj%d]; // E(q) of that joint: parent -> child coordinates (row-major)" % i)
+        A("{ // joint axis of path joint %d in the branch frame, parked for the walks below (zero beyond the root)" % i)
+        A("  const int pa = pc%d & 3; T w[3];" % i)
+        A("  #pragma unroll")
+        A("  for (int r = 0; r < 3; r++) { const T wr = (pa == 0) ? Rc[3*r] : ((pa == 1) ? Rc[3*r + 1] : Rc[3*r + 2]); w[r] = pv%d ? wr : Z; }" % i)
+        A("  s_sp_dst[%d] = w[0]; s_sp_dst[%d] = w[1]; s_sp_dst[%d] = w[2];" % (6 * i, 6 * i + 1, 6 * i + 2))
+        A("  s_sp_dst[%d] = pc[1]*w[2] - pc[2]*w[1]; s_sp_dst[%d] = pc[2]*w[0] - pc[0]*w[2]; s_sp_dst[%d] = pc[0]*w[1] - pc[1]*w[0]; }" % (6 * i + 3, 6 * i + 4, 6 * i + 5))
         A("T Rn[9];")
         A("#pragma unroll")
         A("for (int r = 0; r < 3; r++) {", True)
@@ -352,12 +360,13 @@ def gen_forward_dynamics_gradient_inner_branch(self, use_thread_group=False):
         A("for (int c = 0; c < 3; c++) { Rn[3*r + c] = Rc[3*r]*Ei[c] + Rc[3*r + 1]*Ei[3 + c] + Rc[3*r + 2]*Ei[6 + c]; }")
         self.gen_add_end_control_flow()
         if i in root_steps:
-            A("if (plen == %d) { gvec[0] = gravity*Rn[2]; gvec[1] = gravity*Rn[5]; gvec[2] = gravity*Rn[8]; } // base acceleration (0,0,g) in this branch's coordinates" % (i + 1))
+            A("gvec[0] = (plen == %d) ? gravity*Rn[2] : gvec[0]; gvec[1] = (plen == %d) ? gravity*Rn[5] : gvec[1]; gvec[2] = (plen == %d) ? gravity*Rn[8] : gvec[2]; // base acceleration (0,0,g) in this branch's coordinates" % (i + 1, i + 1, i + 1))
         if i < D - 1:
             A("#pragma unroll")
             A("for (int r = 0; r < 3; r++) { pc[r] -= Rn[3*r]*rj[%d][0] + Rn[3*r + 1]*rj[%d][1] + Rn[3*r + 2]*rj[%d][2]; }" % (i, i, i))
             A("#pragma unroll")
             A("for (int r = 0; r < 9; r++) { Rc[r] = Rn[r]; }")
+            A("GRID_SCHED_FENCE();")
         self.gen_add_end_control_flow()
     self.gen_add_end_control_flow()
     self.gen_add_sync(use_thread_group)

@@ -47,7 +47,7 @@ def gen_lds_layout(self):
     off["FD_TOTAL"] = cur
     if getattr(self, "branch_frame", False):
         off["FD_SP"] = off["U"]
-        off["FD_QDD"] = off["FD_SP"] + _pad4(6 * self.branch_plan["D"] * self.branch_plan["nb"])
+        off["FD_QDD"] = off["FD_SP"] + _pad4(6 * self.branch_plan["D"] * (self.branch_plan["nb"] + 1))
         tot = off["FD_QDD"] + _pad4(n)
         if (tot // 4) % 2 == 0:
             tot += 4
