@@ -100,12 +100,18 @@ class GRiDCodeGenerator:
         self.tip_frame = tip_ok and mode in ("auto", "tipframe") and not DEBUG_MODE  # (DEBUG_MODE prints M^-1, which this path never forms)
         # branched robots with revolute joints: forward_dynamics_gradient with every branch in the frame of its own tip link
         # (algorithms/_branch_frame_gradient.py); the other kernels of such robots stay on the column walk
-        self.branch_plan = self.gen_branch_frame_plan() if (COLS_PER_LANE == 2 and not DEBUG_MODE and not self.tip_frame and mode in ("auto", "branch")) else None
+        # Long chains too: the tip-frame inner replicates the dense factorisation in registers (12-DoF chain: 552 B of scratch, 75 us per 16 384
+        # solves) where the branch-frame inner keeps its factors in LDS (46 us); measured the other way round for 8 joints (18 vs 13 us).
+        want_branch = mode == "branch" or (mode == "auto" and (not self.tip_frame or self.tip_L >= 10))
+        self.branch_plan = self.gen_branch_frame_plan() if (COLS_PER_LANE == 2 and not DEBUG_MODE and want_branch) else None
         if mode == "branch" and self.branch_plan is None:
             raise NotImplementedError("GRID_GRADIENT_WALK=branch needs revolute joints and branches that fit the 16-lane rows of the lane group")
         self.branch_frame = self.branch_plan is not None
-        if self.branch_frame:
+        if mode == "branch":
+            self.tip_frame = False
+        if self.branch_frame and not self.tip_frame:
             self.tip_L = self.branch_plan["maxLb"]  # (length of the DPP scans)
+        self.branch_tab_offset = 54 * n + (len(self.gen_tip_frame_link_constants()) if self.tip_frame else 0)
         self.reuse_rnea = self.register_walk and n <= 9 and _os.environ.get("GRID_FUSE_FD", "1") == "1" and _os.environ.get("GRID_REUSE_RNEA", "0") == "1"  # measured: 16.6 us vs 15.0 us per launch with re-use (extra LDS traffic on the critical path), so off by default
         # tuning knob: minimum waves per SIMD the register allocator must leave room for (second __launch_bounds__ argument); 0 = compiler's choice
         self.min_waves_per_eu = int(__import__("os").environ.get("GRID_MIN_WAVES", "0"))

@@ -253,7 +253,7 @@ def gen_forward_dynamics_gradient_inner_branch(self, use_thread_group=False):
     D, maxLb, maxlevel, maxchild, RL = P["D"], P["maxLb"], P["maxlevel"], P["maxchild"], P["row_len"]
     lanes = self.lanes_per_solve
     ld = self.minv_ld
-    tab = 54 * n
+    tab = self.branch_tab_offset
     roff = tab + RL * lanes
     H = 24
     A = self.gen_add_code_line

@@ -30,11 +30,11 @@ def gen_forward_dynamics_gradient_inner_python(self, use_thread_group=False, use
     n = self.model.n
     import os
     stop = int(os.environ.get("GRID_DEBUG_STOP", "0"))  # timing ablation only (results are wrong when set): 1 = X update, 2 = +Minv, 3 = +RNEA/qdd, 4 = +gradient walk
-    if self.tip_frame and stop in (0, 5, 6, 7, 20):  # serial revolute chains: everything after the X update is one fused inner in the tip link's frame
-        self.gen_forward_dynamics_gradient_inner_tip_function_call(use_thread_group, use_qdd_Minv_input, s_df_du_name)
-        return
     if getattr(self, "branch_frame", False) and stop in (0, 20) and not use_qdd_Minv_input:  # trees of revolute joints: one fused inner, every branch in its tip link's frame
         self.gen_forward_dynamics_gradient_inner_branch_function_call(use_thread_group, s_df_du_name)
+        return
+    if self.tip_frame and stop in (0, 5, 6, 7, 20):  # serial revolute chains: everything after the X update is one fused inner in the tip link's frame
+        self.gen_forward_dynamics_gradient_inner_tip_function_call(use_thread_group, use_qdd_Minv_input, s_df_du_name)
         return
     if stop == 1:
         self.gen_add_code_line("if (lane < %d) { %s[lane] = s_X[GRID_X_STRIDE*lane]; }" % (n, s_df_du_name))

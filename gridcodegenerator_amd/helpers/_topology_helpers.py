@@ -82,7 +82,8 @@ def gen_model_constant_table(self):
         vals += [m.I[i][row, col] for col in range(6) for row in range(6)]
     if getattr(self, "tip_frame", False):  # one 12-float row of link constants per lane of the lane group (tip-frame gradient path)
         vals += self.gen_tip_frame_link_constants()
-    elif getattr(self, "branch_frame", False):  # per-lane rows of the branch-frame gradient path
+    if getattr(self, "branch_frame", False):  # per-lane rows of the branch-frame gradient path
+        assert len(vals) == self.branch_tab_offset
         vals += self.gen_branch_frame_constants()
     for ctype, sfx in (("float", "f"), ("double", "")):
         self.gen_add_code_line("__device__ const %s grid_model_constants_%s[%d] = {" % (ctype, ctype, len(vals)), True)

@@ -1,12 +1,16 @@
 """Secondary configurations (BASELINE.json configs 2-4): forward_dynamics_gradient throughput of every fixture robot."""
-import sys, time, json
+import sys, time, json, os
 sys.path.insert(0, ".")
+BUILD_DIR = os.environ.get("GRID_SWEEP_BUILD_DIR")  # experimental build instead of the shipped one
+ONLY = sys.argv[1:]  # optional robot names
 import numpy as np, torch
 from gridcodegenerator_amd import RobotModel
 from gridcodegenerator_amd.runtime import load
-for name, N in (("iiwa14", 1024), ("iiwa14", 16384), ("iiwa14", 131072), ("hyq", 4096), ("hyq", 65536), ("atlas", 2048), ("atlas", 16384), ("arm6", 16384), ("chain12", 16384)):
+for name, N in (("iiwa14", 1024), ("iiwa14", 16384), ("iiwa14", 131072), ("hyq", 4096), ("hyq", 65536), ("atlas", 2048), ("atlas", 16384), ("arm6", 16384), ("chain12", 16384), ("chain8", 16384), ("tree12", 16384)):
+    if ONLY and name not in ONLY:
+        continue
     robot = RobotModel.from_fixture(name); n = robot.n
-    lib = load(name, max_timesteps=N)
+    lib = load(name, max_timesteps=N, build_dir=BUILD_DIR)
     rng = np.random.default_rng(0)
     x = np.hstack([rng.uniform(-np.pi, np.pi, (N, n)), rng.uniform(-2, 2, (N, n)), rng.uniform(-10, 10, (N, n))]).astype(np.float32)
     d_in = torch.from_numpy(x).cuda(); d_out = torch.empty((N, 2*n*n), dtype=torch.float32, device="cuda")
