@@ -46,7 +46,7 @@ class GRiDCodeGenerator:
         gen_tip_frame_link_constants, gen_tip_frame_joint_offset, gen_tip_frame_library, gen_forward_dynamics_gradient_inner_tip, \
         gen_forward_dynamics_gradient_inner_tip_function_call, gen_tip_frame_gradient, \
         gen_inverse_dynamics_inner_tip, gen_inverse_dynamics_gradient_inner_tip, gen_forward_dynamics_inner_tip, gen_direct_minv_inner_tip, gen_tip_frame_components, \
-        gen_branch_frame_plan, gen_branch_frame_constants, gen_branch_frame_library, gen_forward_dynamics_gradient_inner_branch, \
+        gen_branch_frame_plan, gen_branch_frame_constants, gen_branch_frame_library, gen_branch_frame_components, gen_forward_dynamics_gradient_inner_branch, \
         gen_forward_dynamics_gradient_inner_branch_function_call
 
     # NumPy debug helpers with the reference's names and signatures (reference GRiDCodeGenerator.py:50-51, README "Additional Features")
@@ -112,6 +112,7 @@ class GRiDCodeGenerator:
         if self.branch_frame and not self.tip_frame:
             self.tip_L = self.branch_plan["maxLb"]  # (length of the DPP scans)
         self.branch_tab_offset = 54 * n + (len(self.gen_tip_frame_link_constants()) if self.tip_frame else 0)
+        self.branch_components = self.branch_frame and not self.tip_frame  # the stand-alone kernels of branched robots run the same path
         self.reuse_rnea = self.register_walk and n <= 9 and _os.environ.get("GRID_FUSE_FD", "1") == "1" and _os.environ.get("GRID_REUSE_RNEA", "0") == "1"  # measured: 16.6 us vs 15.0 us per launch with re-use (extra LDS traffic on the critical path), so off by default
         # tuning knob: minimum waves per SIMD the register allocator must leave room for (second __launch_bounds__ argument); 0 = compiler's choice
         self.min_waves_per_eu = int(__import__("os").environ.get("GRID_MIN_WAVES", "0"))
@@ -174,7 +175,7 @@ class GRiDCodeGenerator:
                                  "const int GRID_OUT_PER_SOLVE = " + str(lds["OUT_PER_SOLVE"]) + "; // output staging per lane group, placed behind the block's slices",
                                  "// a block of t threads needs (t/GRID_LANES_PER_SOLVE)*(GRID_LDS_PER_SOLVE+GRID_OUT_PER_SOLVE)*sizeof(T) bytes of dynamic LDS;",
                                  "// the *_DYNAMIC_SHARED_MEM_COUNT constants below are that amount for SUGGESTED_THREADS"])
-        for k in ("IN", "X", "U", "T", "MINV", "QDD", "F", "J"):
+        for k in ("IN", "X", "U", "T", "MINV", "QDD", "F", "J", "SP"):
             self.gen_add_code_line("const int GRID_OFF_" + k + " = " + str(lds[k]) + ";")
         fd_threads = self.suggested_threads
         if lds["FD_TOTAL"] < lds["TOTAL"]:  # LDS-capacity-bound kernels: one wave per block packs the CU's 160 KB best
@@ -356,6 +357,8 @@ class GRiDCodeGenerator:
         self.gen_load_update_XImats_helpers(use_thread_group)
         if self.tip_frame:
             self.gen_tip_frame_components(use_thread_group)
+        elif self.branch_frame:
+            self.gen_branch_frame_components(use_thread_group)
         # the dynamics algorithms on (and next to) the forward-dynamics-gradient path
         self.gen_inverse_dynamics(use_thread_group)
         self.gen_direct_minv(use_thread_group)

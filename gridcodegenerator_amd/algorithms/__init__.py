@@ -10,5 +10,5 @@ from ._forward_dynamics_gradient import *
 from ._tip_frame_gradient import gen_tip_frame_link_constants, gen_tip_frame_joint_offset, gen_tip_frame_library, \
     gen_forward_dynamics_gradient_inner_tip, gen_forward_dynamics_gradient_inner_tip_function_call, gen_tip_frame_gradient, \
     gen_inverse_dynamics_inner_tip, gen_inverse_dynamics_gradient_inner_tip, gen_forward_dynamics_inner_tip, gen_direct_minv_inner_tip, gen_tip_frame_components
-from ._branch_frame_gradient import gen_branch_frame_plan, gen_branch_frame_constants, gen_branch_frame_library, \
+from ._branch_frame_gradient import gen_branch_frame_plan, gen_branch_frame_constants, gen_branch_frame_library, gen_branch_frame_components, \
     gen_forward_dynamics_gradient_inner_branch, gen_forward_dynamics_gradient_inner_branch_function_call

@@ -191,10 +191,10 @@ __device__ __forceinline__ void grid_force_up(T *y, const T (&R)[9], const T (&p
     grid_rt3(y, R, f[0] - (p[1]*f[5] - p[2]*f[4]), f[1] - (p[2]*f[3] - p[0]*f[5]), f[2] - (p[0]*f[4] - p[1]*f[3]));
     grid_rt3(y + 3, R, f[3], f[4], f[5]);
 }
-// composite inertia (10), Coriolis matrix (12) and force (6) of a whole branch, re-expressed in the parent branch's frame: y[28]
+// composite inertia (10) of a whole branch, re-expressed in the parent branch's frame: origin shift (c' = c - p), then rotation
 template <typename T>
-__device__ __forceinline__ void grid_junction_up(T (&y)[28], const T (&R)[9], const T (&p)[3], const T (&I)[10], const T (&B)[12], const T (&f)[6]) {
-    {   // inertia: origin shift (c' = c - p), then rotation
+__device__ __forceinline__ void grid_inertia_up(T *y, const T (&R)[9], const T (&p)[3], const T (&I)[10]) {
+    {
         const T m = I[9];
         const T s = static_cast<T>(-2)*(I[6]*p[0] + I[7]*p[1] + I[8]*p[2]) + m*(p[0]*p[0] + p[1]*p[1] + p[2]*p[2]);
         T A[6];
@@ -208,7 +208,11 @@ __device__ __forceinline__ void grid_junction_up(T (&y)[28], const T (&R)[9], co
         grid_rt3(&y[6], R, I[6] - m*p[0], I[7] - m*p[1], I[8] - m*p[2]);
         y[9] = m;
     }
-    {   // Coriolis matrix [Sym | n | l]: Sym' = Sym + l p^T + p l^T - 2 (p.l) 1,  n' = n - p x l,  l' = l
+}
+// composite Coriolis matrix [Sym | n | l] (12): Sym' = Sym + l p^T + p l^T - 2 (p.l) 1,  n' = n - p x l,  l' = l, then rotation
+template <typename T>
+__device__ __forceinline__ void grid_coriolis_up(T *y, const T (&R)[9], const T (&p)[3], const T (&B)[12]) {
+    {
         const T l0 = B[9], l1 = B[10], l2 = B[11];
         const T s = static_cast<T>(-2)*(p[0]*l0 + p[1]*l1 + p[2]*l2);
         T A[6];
@@ -218,11 +222,15 @@ __device__ __forceinline__ void grid_junction_up(T (&y)[28], const T (&R)[9], co
         A[3] = B[3] + s + static_cast<T>(2)*l1*p[1];
         A[4] = B[4] + l1*p[2] + p[1]*l2;
         A[5] = B[5] + s + static_cast<T>(2)*l2*p[2];
-        grid_rt_sym(&y[10], R, A);
-        grid_rt3(&y[16], R, B[6] - (p[1]*l2 - p[2]*l1), B[7] - (p[2]*l0 - p[0]*l2), B[8] - (p[0]*l1 - p[1]*l0));
-        grid_rt3(&y[19], R, l0, l1, l2);
+        grid_rt_sym(&y[0], R, A);
+        grid_rt3(&y[6], R, B[6] - (p[1]*l2 - p[2]*l1), B[7] - (p[2]*l0 - p[0]*l2), B[8] - (p[0]*l1 - p[1]*l0));
+        grid_rt3(&y[9], R, l0, l1, l2);
     }
-    grid_force_up(&y[22], R, p, f);
+}
+// all three: y = [I^C (10) | B^C (12) | f^C (6)]
+template <typename T>
+__device__ __forceinline__ void grid_junction_up(T (&y)[28], const T (&R)[9], const T (&p)[3], const T (&I)[10], const T (&B)[12], const T (&f)[6]) {
+    grid_inertia_up(&y[0], R, p, I); grid_coriolis_up(&y[10], R, p, B); grid_force_up(&y[22], R, p, f);
 }
 """
 
@@ -247,6 +255,37 @@ def _anc_local(sig):
 
 def gen_forward_dynamics_gradient_inner_branch(self, use_thread_group=False):
     """The fused inner of the branch-frame path (u-input form): see the module notes."""
+    _emit_branch_inner(self, "fdgrad", use_thread_group)
+
+
+def gen_branch_frame_components(self, use_thread_group=False):
+    """Stand-alone kernels of branched robots on the same path: subsets of the fused inner."""
+    for mode in ("id", "idgrad", "fd", "minv"):
+        _emit_branch_inner(self, mode, use_thread_group)
+
+
+_BRANCH_MODES = {
+    # mode: (function name, what it computes, leading parameters, their docs)
+    "fdgrad": ("forward_dynamics_gradient_inner_branch", "Computes the gradient of forward dynamics",
+               "T *s_df_du, const T *s_qd, const T *s_u, T *s_X, T *s_SP, T *s_qdd, const robotModel<T> *d_robotModel, const T gravity, const int lane"),
+    "id": ("inverse_dynamics_inner_branch", "Compute the RNEA (Recursive Newton-Euler Algorithm)",
+           "T *s_c, const T *s_qd, const T *s_qddin, T *s_X, T *s_SP, const robotModel<T> *d_robotModel, const T gravity, const int lane"),
+    "idgrad": ("inverse_dynamics_gradient_inner_branch", "Computes the gradient of inverse dynamics",
+               "T *s_dc_du, const T *s_qd, const T *s_qddin, T *s_X, T *s_SP, const robotModel<T> *d_robotModel, const T gravity, const int lane"),
+    "fd": ("forward_dynamics_inner_branch", "Computes forward dynamics",
+           "T *s_qdd, const T *s_qd, const T *s_u, T *s_X, T *s_SP, const robotModel<T> *d_robotModel, const T gravity, const int lane"),
+    "minv": ("direct_minv_inner_branch", "Compute the inverse of the mass matrix (dense, symmetric) into LDS",
+             "T *s_Minv, T *s_X, T *s_SP, const robotModel<T> *d_robotModel, const int lane"),
+}
+
+
+def _emit_branch_inner(self, mode, use_thread_group=False):
+    """One emitter for the five inners of the branch-frame path; `mode` selects the stages (see gen_branch_frame_components)."""
+    grad = mode in ("fdgrad", "idgrad")      # needs the Coriolis composites and the derivative entries
+    kin = mode != "minv"                      # needs velocities / accelerations
+    needs_M = mode in ("fdgrad", "fd", "minv")
+    qdd_in = mode in ("id", "idgrad")        # joint accelerations are an input (id: the pointer may be null = zero)
+    fname, fdoc, fsig = _BRANCH_MODES[mode]
     m = self.model
     n = m.n
     P = self.branch_plan
@@ -257,23 +296,24 @@ def gen_forward_dynamics_gradient_inner_branch(self, use_thread_group=False):
     roff = tab + RL * lanes
     H = 24
     A = self.gen_add_code_line
-    self.gen_add_func_doc("Computes the gradient of forward dynamics, every branch of the tree in the frame of its tip link",
-                          ["robots whose joints are all revolute (see the module notes of algorithms/_branch_frame_gradient.py); same results as",
-                           "direct_minv_inner + inverse_dynamics_inner + inverse_dynamics_gradient_inner",
-                           "s_df_du receives -Minv*dc/du in the device layout [col*n + row]; the caller must grid_wave_sync() before other lanes read it"],
-                          ["s_df_du is a pointer to LDS for the final result of size 2*NUM_JOINTS*NUM_JOINTS = " + str(2 * n * n) + " (also the assembly area of dc/du)",
-                           "s_qd is the vector of joint velocities in LDS", "s_u is the vector of joint input torques in LDS",
-                           "s_X is this solve's compact X(q) storage (the rotation blocks are read; once the frames are known it is re-used for the",
+    outdoc = {"fdgrad": "s_df_du receives -Minv*dc/du in the device layout [col*n + row] (2*NUM_JOINTS*NUM_JOINTS values; also the assembly area of dc/du)",
+              "id": "s_c receives the joint torques (lane of joint j writes s_c[j]); s_qddin may be nullptr (zero accelerations)",
+              "idgrad": "s_dc_du receives dc/du in the device layout [col*n + row], col in [0,2n) = [d/dq | d/dqd]",
+              "fd": "s_qdd receives the joint accelerations (it also holds tau - c on the way)",
+              "minv": "s_Minv receives the dense symmetric inverse of the joint-space inertia (leading dimension GRID_MINV_LD; zero between base-rooted components)"}[mode]
+    self.gen_add_func_doc(fdoc + ", every branch of the tree in the frame of its tip link",
+                          ["robots whose joints are all revolute (see the module notes of algorithms/_branch_frame_gradient.py)", outdoc,
+                           "the caller must grid_wave_sync() before other lanes read the result"],
+                          ["s_X is this solve's compact X(q) storage (the rotation blocks are read; once the frames are known it is re-used for the",
                            "     tree-sparse M, its factors and the branch hand-over records)",
                            "s_SP is LDS scratch for the joint axes along the root path of every branch (6 values per path joint, plus one spare record per solve)",
-                           "s_qdd is LDS scratch for tau - c and then the joint accelerations",
-                           "d_robotModel is the pointer to the initialized model specific helpers on the GPU", "gravity is the gravity constant",
+                           "d_robotModel is the pointer to the initialized model specific helpers on the GPU",
                            "lane is the caller's lane index inside the solve's lane group"], None)
     A("template <typename T>")
     A("__device__ __forceinline__")
-    A("void forward_dynamics_gradient_inner_branch(T *s_df_du, const T *s_qd, const T *s_u, T *s_X, T *s_SP, T *s_qdd, const robotModel<T> *d_robotModel, const T gravity, const int lane) {", True)
+    A("void %s(%s) {" % (fname, fsig), True)
     import os
-    ts_mode = os.environ.get("GRID_DEBUG_STOP", "0") == "20"  # profiling build: per-wave cycle stamps at the phase boundaries replace the first outputs
+    ts_mode = mode == "fdgrad" and os.environ.get("GRID_DEBUG_STOP", "0") == "20"  # profiling build: per-wave cycle stamps at the phase boundaries replace the first outputs
 
     def TS(i):
         if ts_mode:
@@ -297,16 +337,18 @@ def gen_forward_dynamics_gradient_inner_branch(self, use_thread_group=False):
     A("const int own = Lb - 1 - pos; // index of this lane's joint on the root path of its branch (tip -> root); -1 on lanes without a joint")
     A("const int li = jid - cbase;   // index of the joint inside its base-rooted component")
     A("T *s_Sp = &s_SP[%d*slot]; // joint axes along the root path of this lane's branch, in the branch frame" % (6 * D))
-    A("(void)level; (void)plen; (void)s_G; (void)mstart;")
+    A("(void)level; (void)plen; (void)s_G; (void)mstart; (void)s_Mc; (void)s_Uc; (void)s_trash; (void)shape; (void)li; (void)ubase;")
     for i in range(D):
         A("const int pc%d = static_cast<int>(d_L[%d]); const bool pv%d = pc%d >= 0; const int pj%d = pv%d ? (pc%d >> 2) : js; const bool act%d = pv%d && (%d >= own);"
           % (i, H + i, i, i, i, i, i, i, i, i))
-    A("// zero image of dc/du (unrelated joints, and rows outside the component of a column, stay exactly zero)")
+    zero = {"fdgrad": ("s_df_du", 2 * n * n), "idgrad": ("s_dc_du", 2 * n * n), "minv": ("s_Minv", n * ld)}.get(mode)
     A("grid_wave_sync();")
-    A("for (int e = lane; e < %d; e += %d) {" % ((2 * n * n + 3) // 4, lanes), True)
-    A("#pragma unroll")
-    A("for (int r = 0; r < 4; r++) { s_df_du[4*e + r] = Z; }")
-    self.gen_add_end_control_flow()
+    if zero is not None:
+        A("// zero image of the result (unrelated joints, and rows outside the component of a column, stay exactly zero)")
+        A("for (int e = lane; e < %d; e += %d) {" % ((zero[1] + 3) // 4, lanes), True)
+        A("#pragma unroll")
+        A("for (int r = 0; r < 4; r++) { %s[4*e + r] = Z; }" % zero[0])
+        self.gen_add_end_control_flow()
     # ------------------------------------------------------------------ frame chain along the root path
     TS(1)
     A("//")
@@ -359,7 +401,7 @@ def gen_forward_dynamics_gradient_inner_branch(self, use_thread_group=False):
         A("#pragma unroll")
         A("for (int c = 0; c < 3; c++) { Rn[3*r + c] = Rc[3*r]*Ei[c] + Rc[3*r + 1]*Ei[3 + c] + Rc[3*r + 2]*Ei[6 + c]; }")
         self.gen_add_end_control_flow()
-        if i in root_steps:
+        if i in root_steps and kin:
             A("gvec[0] = (plen == %d) ? gravity*Rn[2] : gvec[0]; gvec[1] = (plen == %d) ? gravity*Rn[5] : gvec[1]; gvec[2] = (plen == %d) ? gravity*Rn[8] : gvec[2]; // base acceleration (0,0,g) in this branch's coordinates" % (i + 1, i + 1, i + 1))
         if i < D - 1:
             A("#pragma unroll")
@@ -381,7 +423,10 @@ def gen_forward_dynamics_gradient_inner_branch(self, use_thread_group=False):
         A("mkd[0] = Z;")
     for s_, k in enumerate(steps):
         A("mkd[%d] = (pos + %d < Lb) ? static_cast<T>(1) : Z;" % (s_, k))
-    A("const T qd = active ? s_qd[js] : Z;")
+    if kin:
+        A("const T qd = active ? s_qd[js] : Z;")
+    else:
+        A("(void)gvec;")
     A("T S[6];")
     A("{ const int ax = static_cast<int>(Lc[11]);")
     A("  #pragma unroll")
@@ -407,24 +452,28 @@ def gen_forward_dynamics_gradient_inner_branch(self, use_thread_group=False):
             A("I[%d] = %s - md%d*d[%d];" % (k, rot, r_, c_))
     A("I[6] = md0; I[7] = md1; I[8] = md2; I[9] = Lc[9];")
     self.gen_add_end_control_flow()
-    A("const T damping = Lc[10];")
+    A("const T damping = Lc[10]; (void)damping;")
 
     def walk_open(with_qdd):
         """Software-pipelined walk along the root path, root -> tip: the LDS reads of step i-1 are issued before the arithmetic of step i and
         a scheduling fence closes every step (otherwise the compiler hoists all the loads of the walk to its top and spills)."""
-        A("T Sn[6], qdn%s;" % (", qddn" if with_qdd else ""))
+        A("T Sn[6]%s%s;" % (", qdn" if kin else "", ", qddn" if with_qdd else ""))
         walk_fetch(D - 1, with_qdd)
 
     def walk_fetch(i, with_qdd):
         A("#pragma unroll")
         A("for (int r = 0; r < 6; r++) { Sn[r] = s_Sp[%d + r]; }" % (6 * i))
-        A("qdn = act%d ? s_qd[pj%d] : Z;" % (i, i))
+        if kin:
+            A("qdn = act%d ? s_qd[pj%d] : Z;" % (i, i))
         if with_qdd:
-            A("qddn = act%d ? s_qdd[pj%d] : Z;" % (i, i))
+            if mode == "id":
+                A("qddn = (act%d && s_qddin != nullptr) ? s_qddin[pj%d] : Z;" % (i, i))
+            else:
+                A("qddn = act%d ? %s[pj%d] : Z;" % (i, "s_qddin" if qdd_in else "s_qdd", i))
 
     def walk_step(i, with_qdd):
         A("{ // path step %d" % i, True)
-        A("T Spi[6]; const T qdi = qdn;%s" % (" const T qddi = qddn;" if with_qdd else ""))
+        A("T Spi[6];%s%s" % (" const T qdi = qdn;" if kin else "", " const T qddi = qddn;" if with_qdd else ""))
         A("#pragma unroll")
         A("for (int r = 0; r < 6; r++) { Spi[r] = Sn[r]; }")
         if i > 0:
@@ -434,89 +483,173 @@ def gen_forward_dynamics_gradient_inner_branch(self, use_thread_group=False):
         A("GRID_SCHED_FENCE();")
         self.gen_add_end_control_flow()
 
-    A("T v[6] = {Z, Z, Z, Z, Z, Z}, a[6] = {Z, Z, Z, Z, Z, Z};")
-    A("{", True)
-    walk_open(False)
-    for i in range(D - 1, -1, -1):
-        walk_step(i, False)
-        A("T Pdi[6];")
-        A("#pragma unroll")
-        A("for (int r = 0; r < 6; r++) { v[r] += Spi[r]*qdi; }")
-        A("grid_mxm(Pdi, v, Spi);")
-        A("#pragma unroll")
-        A("for (int r = 0; r < 6; r++) { a[r] += Pdi[r]*qdi; }")
-        walk_close()
-    self.gen_add_end_control_flow()
-    A("a[3] += gvec[0]; a[4] += gvec[1]; a[5] += gvec[2];")
-    A("T Pd[6]; grid_mxm(Pd, v, S); // = S-dot of the own joint")
+    if kin:
+        A("T v[6] = {Z, Z, Z, Z, Z, Z}, a[6] = {Z, Z, Z, Z, Z, Z};")
+        A("{", True)
+        walk_open(qdd_in)
+        for i in range(D - 1, -1, -1):
+            walk_step(i, qdd_in)
+            A("T Pdi[6];")
+            A("#pragma unroll")
+            A("for (int r = 0; r < 6; r++) { v[r] += Spi[r]*qdi; }")
+            A("grid_mxm(Pdi, v, Spi);")
+            A("#pragma unroll")
+            A("for (int r = 0; r < 6; r++) { a[r] += Pdi[r]*qdi%s; }" % (" + Spi[r]*qddi" if qdd_in else ""))
+            walk_close()
+        self.gen_add_end_control_flow()
+        A("a[3] += gvec[0]; a[4] += gvec[1]; a[5] += gvec[2];")
+        A("T Pd[6]; grid_mxm(Pd, v, S); // = S-dot of the own joint")
     # body quantities and composites (as _tip_frame_gradient._emit_bias, with a given)
     TS(3)
     A("T IC[10], BC[12], fC[6];")
-    A("{", True)
-    A("T Iv[6]; grid_rbi_mul(Iv, I, v); // [n; l]: the link's momentum")
-    A("grid_rbi_mul(fC, I, a); grid_fxv_peq(fC, v, Iv);")
-    A("const T A00 = v[1]*I[2] - v[2]*I[1], A01 = v[1]*I[4] - v[2]*I[3], A02 = v[1]*I[5] - v[2]*I[4];")
-    A("const T A10 = v[2]*I[0] - v[0]*I[2], A11 = v[2]*I[1] - v[0]*I[4], A12 = v[2]*I[2] - v[0]*I[5];")
-    A("const T A20 = v[0]*I[1] - v[1]*I[0], A21 = v[0]*I[3] - v[1]*I[1], A22 = v[0]*I[4] - v[1]*I[2];")
-    A("const T uh = static_cast<T>(2)*(v[3]*I[6] + v[4]*I[7] + v[5]*I[8]);")
-    A("BC[0] = static_cast<T>(2)*(A00 - I[6]*v[3]) + uh;")
-    A("BC[1] = A01 + A10 - I[6]*v[4] - I[7]*v[3];")
-    A("BC[2] = A02 + A20 - I[6]*v[5] - I[8]*v[3];")
-    A("BC[3] = static_cast<T>(2)*(A11 - I[7]*v[4]) + uh;")
-    A("BC[4] = A12 + A21 - I[7]*v[5] - I[8]*v[4];")
-    A("BC[5] = static_cast<T>(2)*(A22 - I[8]*v[5]) + uh;")
-    A("#pragma unroll")
-    A("for (int r = 0; r < 6; r++) { BC[6 + r] = Iv[r]; }")
-    self.gen_add_end_control_flow()
-    A("#pragma unroll")
-    A("for (int r = 0; r < 10; r++) { IC[r] = I[r]; }")
-    A("grid_suffix_sum(IC, mkd); grid_suffix_sum(BC, mkd); grid_suffix_sum(fC, mkd); // composites over the rest of the branch")
+    if grad:
+        A("{", True)
+        A("T Iv[6]; grid_rbi_mul(Iv, I, v); // [n; l]: the link's momentum")
+        A("grid_rbi_mul(fC, I, a); grid_fxv_peq(fC, v, Iv);")
+        A("const T A00 = v[1]*I[2] - v[2]*I[1], A01 = v[1]*I[4] - v[2]*I[3], A02 = v[1]*I[5] - v[2]*I[4];")
+        A("const T A10 = v[2]*I[0] - v[0]*I[2], A11 = v[2]*I[1] - v[0]*I[4], A12 = v[2]*I[2] - v[0]*I[5];")
+        A("const T A20 = v[0]*I[1] - v[1]*I[0], A21 = v[0]*I[3] - v[1]*I[1], A22 = v[0]*I[4] - v[1]*I[2];")
+        A("const T uh = static_cast<T>(2)*(v[3]*I[6] + v[4]*I[7] + v[5]*I[8]);")
+        A("BC[0] = static_cast<T>(2)*(A00 - I[6]*v[3]) + uh;")
+        A("BC[1] = A01 + A10 - I[6]*v[4] - I[7]*v[3];")
+        A("BC[2] = A02 + A20 - I[6]*v[5] - I[8]*v[3];")
+        A("BC[3] = static_cast<T>(2)*(A11 - I[7]*v[4]) + uh;")
+        A("BC[4] = A12 + A21 - I[7]*v[5] - I[8]*v[4];")
+        A("BC[5] = static_cast<T>(2)*(A22 - I[8]*v[5]) + uh;")
+        A("#pragma unroll")
+        A("for (int r = 0; r < 6; r++) { BC[6 + r] = Iv[r]; }")
+        self.gen_add_end_control_flow()
+    elif kin:
+        A("{ T Iv[6]; grid_rbi_mul(Iv, I, v); grid_rbi_mul(fC, I, a); grid_fxv_peq(fC, v, Iv); } // the link's force; no Coriolis matrix needed")
+    use_I = mode != "id"   # composite inertia
+    use_B = grad            # composite Coriolis matrix
+    use_f = kin             # composite force
+    if not use_B:
+        A("(void)BC;")
+    if not use_f:
+        A("(void)fC;")
+    if use_I:
+        A("#pragma unroll")
+        A("for (int r = 0; r < 10; r++) { IC[r] = I[r]; }")
+        A("grid_suffix_sum(IC, mkd);")
+    else:
+        A("(void)IC;")
+    if use_B:
+        A("grid_suffix_sum(BC, mkd);")
+    if use_f:
+        A("grid_suffix_sum(fC, mkd);")
+    A("// (composites over the rest of the branch so far)")
     for lv in range(maxlevel, 0, -1):
         A("{ // tree level %d -> %d: branch totals re-expressed in the parent branch's frame and handed to all of its lanes" % (lv, lv - 1), True)
-        A("T y[28]; grid_junction_up(y, TR, Tp, IC, BC, fC);")
+        A("T y[28];")
+        if use_I:
+            A("grid_inertia_up(&y[0], TR, Tp, IC);")
+        if use_B:
+            A("grid_coriolis_up(&y[10], TR, Tp, BC);")
+        if use_f:
+            A("grid_force_up(&y[22], TR, Tp, fC);")
         A("if (active && level == %d && pos == 0) {" % lv, True)
-        A("#pragma unroll")
-        A("for (int r = 0; r < 28; r++) { s_G[28*slot + r] = y[r]; }")
+        for (u_, lo_, hi_) in ((use_I, 0, 10), (use_B, 10, 22), (use_f, 22, 28)):
+            if u_:
+                A("#pragma unroll")
+                A("for (int r = %d; r < %d; r++) { s_G[28*slot + r] = y[r]; }" % (lo_, hi_))
         self.gen_add_end_control_flow()
         self.gen_add_sync(use_thread_group)
         for c in range(maxchild):
             A("{ const int cs = cs%d;" % c)
             A("  if (level == %d && cs >= 0) {" % (lv - 1), True)
             A("const T *g = &s_G[28*cs];")
-            A("#pragma unroll")
-            A("for (int r = 0; r < 10; r++) { IC[r] += g[r]; }")
-            A("#pragma unroll")
-            A("for (int r = 0; r < 12; r++) { BC[r] += g[10 + r]; }")
-            A("#pragma unroll")
-            A("for (int r = 0; r < 6; r++) { fC[r] += g[22 + r]; }")
+            if use_I:
+                A("#pragma unroll")
+                A("for (int r = 0; r < 10; r++) { IC[r] += g[r]; }")
+            if use_B:
+                A("#pragma unroll")
+                A("for (int r = 0; r < 12; r++) { BC[r] += g[10 + r]; }")
+            if use_f:
+                A("#pragma unroll")
+                A("for (int r = 0; r < 6; r++) { fC[r] += g[22 + r]; }")
             self.gen_add_end_control_flow()
             A("}")
         self.gen_add_end_control_flow()
+    if mode == "id":
+        A("if (active) { s_c[jid] = grid_dot6(S, fC) + damping*qd; }")
+        self.gen_add_end_function()
+        return
+    if mode == "idgrad":
+        # accelerations are an input: one walk produces every entry of dc/du that couples this joint with its ancestors
+        A("T t1[6], t2[6], t3[6], t4[3], Pdd[6];")
+        A("grid_mxm(Pdd, a, S); grid_mxm_peq(Pdd, v, Pd);")
+        A("grid_rbi_mul(t1, IC, S);")
+        A("grid_bmul(t2, BC, S); grid_rbi_mul_peq(t2, IC, Pd, static_cast<T>(2));")
+        A("grid_bmul(t3, BC, Pd); grid_rbi_mul_peq(t3, IC, Pdd, static_cast<T>(1)); grid_fxv_peq(t3, S, fC);")
+        A("grid_btmul(t4, BC, S);")
+        A("{", True)
+        A("T vr[6] = {Z, Z, Z, Z, Z, Z}, ar[6] = {Z, Z, Z, gvec[0], gvec[1], gvec[2]};")
+        walk_open(True)
+        for i in range(D - 1, -1, -1):
+            walk_step(i, True)
+            A("T Pdi[6], Pddi[6];")
+            A("#pragma unroll")
+            A("for (int r = 0; r < 6; r++) { vr[r] += Spi[r]*qdi; }")
+            A("grid_mxm(Pdi, vr, Spi);")
+            A("#pragma unroll")
+            A("for (int r = 0; r < 6; r++) { ar[r] += Pdi[r]*qdi + Spi[r]*qddi; }")
+            A("grid_mxm(Pddi, ar, Spi); grid_mxm_peq(Pddi, vr, Pdi);")
+            A("const T up_q = grid_dot6(Spi, t3), up_d = grid_dot6(Spi, t2);")
+            A("const T lo_q = grid_dot6(t1, Pddi) + t4[0]*Pdi[0] + t4[1]*Pdi[1] + t4[2]*Pdi[2];")
+            A("const T lo_d = static_cast<T>(2)*grid_dot6(t1, Pdi) + t4[0]*Spi[0] + t4[1]*Spi[1] + t4[2]*Spi[2];")
+            A("*(act%d ? &s_dc_du[jid*%d + pj%d] : s_trash) = up_q;" % (i, n, i))
+            A("*(act%d ? &s_dc_du[(%d + jid)*%d + pj%d] : s_trash) = up_d + ((own == %d) ? damping : Z); // + damping on the diagonal (oracle _test.py:486)" % (i, n, n, i, i))
+            A("*((act%d && own != %d) ? &s_dc_du[pj%d*%d + jid] : s_trash) = lo_q;" % (i, i, i, n))
+            A("*((act%d && own != %d) ? &s_dc_du[(%d + pj%d)*%d + jid] : s_trash) = lo_d;" % (i, i, n, i, n))
+            walk_close()
+        self.gen_add_end_control_flow()
+        self.gen_add_end_function()
+        return
     # ------------------------------------------------------------------ pass 1
     TS(4)
-    A("// everything that does not depend on qdd: t1, t2, t4, tau - c; then the entries that couple this joint with its ancestors")
-    A("T t1[6], t4[3];")
-    A("grid_rbi_mul(t1, IC, S);")
-    A("grid_btmul(t4, BC, S);")
-    A("if (active) { s_qdd[jid] = s_u[jid] - (grid_dot6(S, fC) + damping*qd); }")
-    A("{", True)
-    A("T t2[6]; grid_bmul(t2, BC, S); grid_rbi_mul_peq(t2, IC, Pd, static_cast<T>(2));")
-    A("T vr[6] = {Z, Z, Z, Z, Z, Z};")
-    walk_open(False)
-    for i in range(D - 1, -1, -1):
-        walk_step(i, False)
-        A("T Pdi[6];")
+    if mode == "fdgrad":
+        A("// everything that does not depend on qdd: t1, t2, t4, tau - c; then the entries that couple this joint with its ancestors")
+        A("T t1[6], t4[3];")
+        A("grid_rbi_mul(t1, IC, S);")
+        A("grid_btmul(t4, BC, S);")
+        A("if (active) { s_qdd[jid] = s_u[jid] - (grid_dot6(S, fC) + damping*qd); }")
+        A("{", True)
+        A("T t2[6]; grid_bmul(t2, BC, S); grid_rbi_mul_peq(t2, IC, Pd, static_cast<T>(2));")
+        A("T vr[6] = {Z, Z, Z, Z, Z, Z};")
+        walk_open(False)
+        for i in range(D - 1, -1, -1):
+            walk_step(i, False)
+            A("T Pdi[6];")
+            A("#pragma unroll")
+            A("for (int r = 0; r < 6; r++) { vr[r] += Spi[r]*qdi; }")
+            A("grid_mxm(Pdi, vr, Spi);")
+            A("const T mkj = grid_dot6(Spi, t1), up_d = grid_dot6(Spi, t2);")
+            A("const T lo_d = static_cast<T>(2)*grid_dot6(t1, Pdi) + t4[0]*Spi[0] + t4[1]*Spi[1] + t4[2]*Spi[2];")
+            A("// (branch-free: lanes that have no such entry write to a spare word)")
+            A("*(act%d ? &s_Mc[mstart + plen - %d] : s_trash) = mkj; // (ancestors in ascending order, then the diagonal)" % (i, i + 1))
+            A("*(act%d ? &s_df_du[(%d + jid)*%d + pj%d] : s_trash) = up_d + ((own == %d) ? damping : Z); // + damping on the diagonal (oracle _test.py:486)" % (i, n, n, i, i))
+            A("*((act%d && own != %d) ? &s_df_du[(%d + pj%d)*%d + jid] : s_trash) = lo_d;" % (i, i, n, i, n))
+            walk_close()
+        self.gen_add_end_control_flow()
+    else:  # fd, minv: only the joint-space inertia, M[i][k] = S_i . (I^C_k S_k) for the ancestors-or-self i of this lane's joint k
+        A("T t1[6]; grid_rbi_mul(t1, IC, S);")
+        if mode == "fd":
+            A("if (active) { s_qdd[jid] = s_u[jid] - (grid_dot6(S, fC) + damping*qd); }")
+        A("{", True)
+        A("T Sn[6];")
         A("#pragma unroll")
-        A("for (int r = 0; r < 6; r++) { vr[r] += Spi[r]*qdi; }")
-        A("grid_mxm(Pdi, vr, Spi);")
-        A("const T mkj = grid_dot6(Spi, t1), up_d = grid_dot6(Spi, t2);")
-        A("const T lo_d = static_cast<T>(2)*grid_dot6(t1, Pdi) + t4[0]*Spi[0] + t4[1]*Spi[1] + t4[2]*Spi[2];")
-        A("// (branch-free: lanes that have no such entry write to a spare word)")
-        A("*(act%d ? &s_Mc[mstart + plen - %d] : s_trash) = mkj; // (ancestors in ascending order, then the diagonal)" % (i, i + 1))
-        A("*(act%d ? &s_df_du[(%d + jid)*%d + pj%d] : s_trash) = up_d + ((own == %d) ? damping : Z); // + damping on the diagonal (oracle _test.py:486)" % (i, n, n, i, i))
-        A("*((act%d && own != %d) ? &s_df_du[(%d + pj%d)*%d + jid] : s_trash) = lo_d;" % (i, i, n, i, n))
-        walk_close()
-    self.gen_add_end_control_flow()
+        A("for (int r = 0; r < 6; r++) { Sn[r] = s_Sp[%d + r]; }" % (6 * (D - 1)))
+        for i in range(D - 1, -1, -1):
+            A("{ T Spi[6];")
+            A("  #pragma unroll")
+            A("  for (int r = 0; r < 6; r++) { Spi[r] = Sn[r]; }")
+            if i > 0:
+                A("  #pragma unroll")
+                A("  for (int r = 0; r < 6; r++) { Sn[r] = s_Sp[%d + r]; }" % (6 * (i - 1)))
+            A("  *(act%d ? &s_Mc[mstart + plen - %d] : s_trash) = grid_dot6(Spi, t1); // (ancestors in ascending order, then the diagonal)" % (i, i + 1))
+            A("  GRID_SCHED_FENCE(); }")
+        self.gen_add_end_control_flow()
     self.gen_add_sync(use_thread_group)
     # ------------------------------------------------------------------ factorisation per component shape
     TS(5)
@@ -525,7 +658,10 @@ def gen_forward_dynamics_gradient_inner_branch(self, use_thread_group=False):
     ancs = [_anc_local(s_) for s_ in shapes]
     A("// tree-sparse U D U^T of the joint-space inertia of this lane's component (leaves first: no fill-in), wave-uniform inside the component,")
     A("// fused with the forward substitution of tau - c; the first lane of the component parks the factors in the (now free) X(q) storage")
-    A("T bq[%d];" % NCmax)
+    with_rhs = mode in ("fdgrad", "fd")
+    park = mode in ("fdgrad", "minv")
+    if with_rhs:
+        A("T bq[%d];" % NCmax)
     for si, sig in enumerate(shapes):
         Nc = len(sig)
         an = ancs[si]
@@ -536,31 +672,66 @@ def gen_forward_dynamics_gradient_inner_branch(self, use_thread_group=False):
         A("%sif (shape == %d) { // component of %d joints" % ("" if si == 0 else "else ", si, Nc), True)
         for k in range(Nc):
             A(" ".join("T A%d_%d = s_Mc[ubase + %d];" % (i, k, midx[(i, k)]) for i in an[k] + [k]))
-        A("#pragma unroll")
-        A("for (int i = 0; i < %d; i++) { bq[i] = s_qdd[cbase + i]; }" % Nc)
+        if with_rhs:
+            A("#pragma unroll")
+            A("for (int i = 0; i < %d; i++) { bq[i] = s_qdd[cbase + i]; }" % Nc)
         for k in range(Nc - 1, -1, -1):
             A("const T rd%d = grid_rcp(A%d_%d);" % (k, k, k))
             if an[k]:
                 A(" ".join("const T U%d_%d = A%d_%d*rd%d;" % (i, k, i, k, k) for i in an[k]))
                 for j in an[k]:
                     A(" ".join("A%d_%d -= U%d_%d*A%d_%d;" % (i, j, i, k, j, k) for i in an[k] if i <= j))
-                A(" ".join("bq[%d] -= U%d_%d*bq[%d];" % (i, i, k, k) for i in an[k]))
-            A("bq[%d] *= rd%d;" % (k, k))
-        for k in range(1, Nc):
-            if an[k]:
-                A("bq[%d] -= %s;" % (k, " + ".join("U%d_%d*bq[%d]" % (i, k, i) for i in an[k])))
-        A("if (li == 0) { // the first lane of the component parks the factors and qdd", True)
-        for k in range(Nc):
-            A(" ".join(["s_Uc[%d] = U%d_%d;" % (midx[(i, k)], i, k) for i in an[k]] + ["s_Uc[%d] = rd%d;" % (midx[(k, k)], k)]))
-        self.gen_add_end_control_flow()
+                if with_rhs:
+                    A(" ".join("bq[%d] -= U%d_%d*bq[%d];" % (i, i, k, k) for i in an[k]))
+            if with_rhs:
+                A("bq[%d] *= rd%d;" % (k, k))
+        if with_rhs:
+            for k in range(1, Nc):
+                if an[k]:
+                    A("bq[%d] -= %s;" % (k, " + ".join("U%d_%d*bq[%d]" % (i, k, i) for i in an[k])))
+        if park:
+            A("if (li == 0) { // the first lane of the component parks the factors", True)
+            for k in range(Nc):
+                A(" ".join(["s_Uc[%d] = U%d_%d;" % (midx[(i, k)], i, k) for i in an[k]] + ["s_Uc[%d] = rd%d;" % (midx[(k, k)], k)]))
+            self.gen_add_end_control_flow()
         self.gen_add_end_control_flow()
     self.gen_add_sync(use_thread_group)  # every lane has read tau - c
-    for si, sig in enumerate(shapes):
-        A("%sif (shape == %d && li == 0) {" % ("" if si == 0 else "else ", si), True)
-        A("#pragma unroll")
-        A("for (int i = 0; i < %d; i++) { s_qdd[cbase + i] = bq[i]; }" % len(sig))
-        self.gen_add_end_control_flow()
-    self.gen_add_sync(use_thread_group)
+    if with_rhs:
+        for si, sig in enumerate(shapes):
+            A("%sif (shape == %d && li == 0) {" % ("" if si == 0 else "else ", si), True)
+            A("#pragma unroll")
+            A("for (int i = 0; i < %d; i++) { s_qdd[cbase + i] = bq[i]; }" % len(sig))
+            self.gen_add_end_control_flow()
+        self.gen_add_sync(use_thread_group)
+    if mode == "fd":
+        self.gen_add_end_function()
+        return
+    if mode == "minv":
+        A("// M^-1: the lane of joint j solves M x = e_j with the parked factors and writes row j (= column j)")
+        for si, sig in enumerate(shapes):
+            Nc = len(sig)
+            an = ancs[si]
+            midx = {}
+            for k in range(Nc):
+                for i in an[k] + [k]:
+                    midx[(i, k)] = len(midx)
+            A("%sif (shape == %d) {" % ("" if si == 0 else "else ", si), True)
+            A("T x[%d];" % Nc)
+            A("#pragma unroll")
+            A("for (int i = 0; i < %d; i++) { x[i] = (i == li) ? static_cast<T>(1) : Z; }" % Nc)
+            for k in range(Nc - 1, 0, -1):
+                for i in an[k]:
+                    A("x[%d] -= s_Uc[%d]*x[%d];" % (i, midx[(i, k)], k))
+            for k in range(Nc):
+                A("x[%d] *= s_Uc[%d];" % (k, midx[(k, k)]))
+            for k in range(1, Nc):
+                for i in an[k]:
+                    A("x[%d] -= s_Uc[%d]*x[%d];" % (k, midx[(i, k)], i))
+            A("#pragma unroll")
+            A("for (int i = 0; i < %d; i++) { s_Minv[%d*jid + cbase + i] = x[i]; }" % (Nc, ld))
+            self.gen_add_end_control_flow()
+        self.gen_add_end_function()
+        return
     # ------------------------------------------------------------------ pass 2
     TS(6)
     A("// the acceleration-dependent parts: a += sum over the ancestors of S_i qdd_i, f^C += sum over the subtree of I_k da_k")

@@ -196,6 +196,12 @@ def gen_direct_minv_device(self, use_thread_group=False):
         self.gen_add_sync(use_thread_group)
         self.gen_add_end_function()
         return
+    if getattr(self, "branch_components", False):  # branched revolute robots: tree-sparse factorisation of M from the branch-frame composites, one unit-vector solve per lane
+        self.gen_add_code_line("(void)s_T; (void)s_U;")
+        self.gen_add_code_line("direct_minv_inner_branch<T>(s_Minv, s_X, &s_work[GRID_OFF_SP], d_robotModel, lane);")
+        self.gen_add_sync(use_thread_group)
+        self.gen_add_end_function()
+        return
     self.gen_direct_minv_inner_function_call(use_thread_group)
     self.gen_add_end_function()
 

@@ -126,6 +126,12 @@ def gen_forward_dynamics_device(self, use_thread_group=False):
         self.gen_add_sync(use_thread_group)
         self.gen_add_end_function()
         return
+    if getattr(self, "branch_components", False):  # branched revolute robots: M from the branch-frame composites, tree-sparse factorisation
+        self.gen_add_code_line("(void)s_T; (void)s_U; (void)s_Minv;")
+        self.gen_add_code_line("forward_dynamics_inner_branch<T>(s_qdd, s_qd, s_u, s_X, &s_work[GRID_OFF_SP], d_robotModel, gravity, lane);")
+        self.gen_add_sync(use_thread_group)
+        self.gen_add_end_function()
+        return
     self.gen_forward_dynamics_inner_function_call(use_thread_group)
     self.gen_add_end_function()
 

@@ -110,6 +110,11 @@ def gen_inverse_dynamics_device(self, use_thread_group=False, use_qdd_input=Fals
         self.gen_add_sync(use_thread_group)
         self.gen_add_end_function()
         return
+    if getattr(self, "branch_components", False):  # branched revolute robots: RNEA with every branch in its tip link's frame, the lane of joint j produces c[j]
+        self.gen_add_code_line("inverse_dynamics_inner_branch<T>(s_c, s_qd, %s, s_X, &s_work[GRID_OFF_SP], d_robotModel, gravity, lane);" % ("s_qdd" if use_qdd_input else "static_cast<const T *>(nullptr)"))
+        self.gen_add_sync(use_thread_group)
+        self.gen_add_end_function()
+        return
     self.gen_add_code_line("T c[%d];" % n)
     self.gen_inverse_dynamics_inner_function_call(use_thread_group, True, use_qdd_input)
     self.gen_add_code_line("if (lane == 0) {", True)

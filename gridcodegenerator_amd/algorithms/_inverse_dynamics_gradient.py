@@ -355,6 +355,12 @@ def gen_inverse_dynamics_gradient_device(self, use_thread_group=False, use_qdd_i
         self.gen_add_sync(use_thread_group)
         self.gen_add_end_function()
         return
+    if getattr(self, "branch_components", False):  # branched revolute robots: assembled with every branch in its tip link's frame
+        self.gen_add_code_line("(void)s_F; (void)s_J;")
+        self.gen_add_code_line("inverse_dynamics_gradient_inner_branch<T>(s_dc_du, s_qd, s_qdd, s_X, &s_work[GRID_OFF_SP], d_robotModel, gravity, lane);")
+        self.gen_add_sync(use_thread_group)
+        self.gen_add_end_function()
+        return
     self.gen_add_code_line(self.gen_gradient_outputs_decl())
     self.gen_inverse_dynamics_gradient_inner_function_call(use_thread_group)
     self.gen_dc_du_to_lds("s_dc_du")

@@ -35,9 +35,17 @@ def gen_lds_layout(self):
                        ("MINV", n * _pad4(n)),        # dense symmetric M^-1, leading dimension padded to a multiple of 4 (16-byte aligned rows -> ds_read_b128)
                        ("QDD", _pad4(n)),
                        ("F", 0 if self.register_walk else _pad4(6 * n)),                # wave-uniform link forces parked between the two sweeps of the gradient walk
-                       ("J", 0 if self.register_walk else 2 * _pad4(6 * n))):      # velocity Jacobian columns of the current link (published by the d/dqd lanes), double buffered
+                       ("J", 0 if self.register_walk else 2 * _pad4(6 * n)),      # velocity Jacobian columns of the current link (published by the d/dqd lanes), double buffered
+                       ("SP", 0)):  # branch-frame path of the component kernels: joint axes along the root path of every branch (placed below)
         off[name] = cur
         cur += size
+    if getattr(self, "branch_components", False):
+        need = _pad4(6 * self.branch_plan["D"] * (self.branch_plan["nb"] + 1))
+        if cur - off["F"] >= need:
+            off["SP"] = off["F"]  # nothing on this path uses the F | J scratch of the column walk
+        else:
+            off["SP"] = cur
+            cur += need
     if (cur // 4) % 2 == 0:
         cur += 4
     off["TOTAL"] = cur
