@@ -107,10 +107,12 @@ def gen_branch_frame_plan(self):
         at += len(m.ancestors[j]) + 1
     ubase = {cb: mstart[cb] for cb in comps}
     nnz = at
-    if 2 * nnz + 28 * nb + 4 > 20 * n:
-        return None  # (M, its factors and the branch hand-over records live in the X(q) storage once the frames are known)
+    if 2 * nnz + 4 > 20 * n:
+        return None  # (M and its factors live in the X(q) storage once the frames are known)
+    g_in_x = 2 * nnz + 28 * nb + 4 <= 20 * n  # the branch hand-over records too when they fit; else behind the path axes
     return dict(branches=branches, br=br, pb=pb, level=level, paths=paths, joint_of_lane=joint_of_lane, kids=kids, comp_base=comp_base,
-                shapes=shapes, shape_of=shape_of, D=D, maxLb=max(len(J) for J in branches), maxlevel=max(level), maxchild=maxchild, row_len=row_len, nb=nb, ubase=ubase, mstart=mstart, nnz=nnz)
+                shapes=shapes, shape_of=shape_of, D=D, maxLb=max(len(J) for J in branches), maxlevel=max(level), maxchild=maxchild, row_len=row_len, nb=nb, ubase=ubase, mstart=mstart, nnz=nnz, g_in_x=g_in_x,
+                sp_size=6 * D * (nb + 1) + (0 if g_in_x else 28 * nb))
 
 
 def gen_branch_frame_constants(self):
@@ -306,7 +308,7 @@ def _emit_branch_inner(self, mode, use_thread_group=False):
                            "the caller must grid_wave_sync() before other lanes read the result"],
                           ["s_X is this solve's compact X(q) storage (the rotation blocks are read; once the frames are known it is re-used for the",
                            "     tree-sparse M, its factors and the branch hand-over records)",
-                           "s_SP is LDS scratch for the joint axes along the root path of every branch (6 values per path joint, plus one spare record per solve)",
+                           "s_SP is LDS scratch for the joint axes along the root path of every branch (6 values per path joint, plus one spare record per solve%s)" % ("" if P["g_in_x"] else "; then the branch hand-over records"),
                            "d_robotModel is the pointer to the initialized model specific helpers on the GPU",
                            "lane is the caller's lane index inside the solve's lane group"], None)
     A("template <typename T>")
@@ -333,7 +335,10 @@ def _emit_branch_inner(self, mode, use_thread_group=False):
     A("const int cbase = static_cast<int>(d_L[17]), shape = static_cast<int>(d_L[18]), plen = static_cast<int>(d_L[19]), ubase = static_cast<int>(d_L[20]), mstart = static_cast<int>(d_L[21]);")
     for c in range(maxchild):
         A("const int cs%d = static_cast<int>(d_L[%d]); // child branch %d of this lane's branch (-1: none)" % (c, H + D + c, c))
-    A("T *s_Mc = &s_X[0], *s_Uc = &s_X[%d + ubase], *s_G = &s_X[%d], *s_trash = &s_X[%d]; // (valid once the frame chain is done with X(q))" % (P["nnz"], 2 * P["nnz"], 2 * P["nnz"] + 28 * P["nb"]))
+    if P["g_in_x"]:
+        A("T *s_Mc = &s_X[0], *s_Uc = &s_X[%d + ubase], *s_G = &s_X[%d], *s_trash = &s_X[%d]; // (valid once the frame chain is done with X(q))" % (P["nnz"], 2 * P["nnz"], 2 * P["nnz"] + 28 * P["nb"]))
+    else:
+        A("T *s_Mc = &s_X[0], *s_Uc = &s_X[%d + ubase], *s_G = &s_SP[%d], *s_trash = &s_X[%d]; // (s_X: valid once the frame chain is done with X(q))" % (P["nnz"], 6 * D * (P["nb"] + 1), 2 * P["nnz"]))
     A("const int own = Lb - 1 - pos; // index of this lane's joint on the root path of its branch (tip -> root); -1 on lanes without a joint")
     A("const int li = jid - cbase;   // index of the joint inside its base-rooted component")
     A("T *s_Sp = &s_SP[%d*slot]; // joint axes along the root path of this lane's branch, in the branch frame" % (6 * D))

@@ -40,7 +40,7 @@ def gen_lds_layout(self):
         off[name] = cur
         cur += size
     if getattr(self, "branch_components", False):
-        need = _pad4(6 * self.branch_plan["D"] * (self.branch_plan["nb"] + 1))
+        need = _pad4(self.branch_plan["sp_size"])
         if cur - off["F"] >= need:
             off["SP"] = off["F"]  # nothing on this path uses the F | J scratch of the column walk
         else:
@@ -55,7 +55,7 @@ def gen_lds_layout(self):
     off["FD_TOTAL"] = cur
     if getattr(self, "branch_frame", False):
         off["FD_SP"] = off["U"]
-        off["FD_QDD"] = off["FD_SP"] + _pad4(6 * self.branch_plan["D"] * (self.branch_plan["nb"] + 1))
+        off["FD_QDD"] = off["FD_SP"] + _pad4(self.branch_plan["sp_size"])
         tot = off["FD_QDD"] + _pad4(n)
         if (tot // 4) % 2 == 0:
             tot += 4

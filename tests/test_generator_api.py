@@ -83,3 +83,25 @@ def test_numpy_debug_helpers_match_reference_goldens(name, golden):
         assert np.allclose(g.test_minv(q, True), gd["Minv"][k], rtol=1e-9, atol=1e-9)
         assert np.allclose(g.test_rnea_grad(q, qd, gd["qdd"][k]), gd["dc_du"][k], rtol=1e-9, atol=1e-8)
         assert np.allclose(g.test_fd_grad(q, qd, u), gd["df_du"][k], rtol=1e-8, atol=1e-7)
+
+
+def test_formulation_chosen_per_robot():
+    """Which forward-dynamics-gradient formulation every fixture gets (a robot silently falling back to the column walk would still pass
+    the parity tests, only slower): tip frame for short revolute chains and forests of equal chains, branch frames for branched revolute
+    robots (all kernels) and long chains (gradient only), column walk for robots with prismatic joints."""
+    from gridcodegenerator_amd import GRiDCodeGenerator, RobotModel
+    expect = {  # name: (tip_frame, branch_frame, branch_components)
+        "iiwa14": (True, False, False), "arm6": (True, False, False), "chain8": (True, False, False), "hyq": (True, False, False),
+        "chain12": (True, True, False), "atlas": (False, True, True), "tree12": (False, True, True), "mixed5": (False, False, False),
+    }
+    for name, want in expect.items():
+        g = GRiDCodeGenerator(RobotModel.from_fixture(name))
+        assert (g.tip_frame, g.branch_frame, g.branch_components) == want, name
+    plan = GRiDCodeGenerator(RobotModel.from_fixture("tree12")).branch_plan
+    assert plan["maxlevel"] == 2 and len(plan["shapes"]) == 2 and plan["nb"] == 6 and not plan["g_in_x"]
+    plan = GRiDCodeGenerator(RobotModel.from_fixture("atlas")).branch_plan
+    assert plan["maxlevel"] == 1 and plan["D"] == 10 and plan["nnz"] == 150 and sorted(j for j in plan["joint_of_lane"] if j >= 0) == list(range(30))
+    # every branch sits inside one 16-lane row
+    for b, J in enumerate(plan["branches"]):
+        lanes = [plan["joint_of_lane"].index(j) for j in J]
+        assert lanes == list(range(lanes[0], lanes[0] + len(J))) and lanes[0] // 16 == lanes[-1] // 16
