@@ -202,6 +202,16 @@ class GRiDCodeGenerator:
             self.gen_add_code_lines(["const int FDSVA_SO_SUGGESTED_THREADS = 64; // fdsva_so keeps the 4 n^3 idsva_so tensors of every solve in LDS: fewer solves per block",
                                      "const int FDSVA_SO_STAGE_PER_SOLVE = " + str(st_) + "; // df/du (2 n^2, padded) + idsva_so (4 n^3), behind the block's slices",
                                      "const int FDSVA_SO_DYNAMIC_SHARED_MEM_COUNT = (FDSVA_SO_SUGGESTED_THREADS/GRID_LANES_PER_SOLVE)*(GRID_LDS_PER_SOLVE + FDSVA_SO_STAGE_PER_SOLVE);"])
+        self.gen_add_code_lines(["// dynamic LDS (bytes) a launch with `threads` threads per block needs: one slice + one staging record per lane group of the block.",
+                                 "// The host wrappers size their launches with it (the *_DYNAMIC_SHARED_MEM_COUNT constants are this amount for SUGGESTED_THREADS in",
+                                 "// elements of T; a block may not exceed the CU's 160 KB: large robots in double precision need fewer threads per block)",
+                                 "template <typename T>",
+                                 "__host__ inline size_t grid_lds_bytes(const dim3 threads, const int lds_per_solve = GRID_LDS_PER_SOLVE, const int out_per_solve = GRID_OUT_PER_SOLVE) {",
+                                 "    int gpb = static_cast<int>(threads.x*threads.y)/GRID_LANES_PER_SOLVE;",
+                                 "    if (gpb > GRID_MAX_SOLVES_PER_BLOCK) {gpb = GRID_MAX_SOLVES_PER_BLOCK;}",
+                                 "    if (gpb < 1) {gpb = 1;}",
+                                 "    return static_cast<size_t>(gpb)*(lds_per_solve + out_per_solve)*sizeof(T);",
+                                 "}"])
         self.gen_add_code_line("// Define custom structs")
         self.gen_add_code_lines(["template <typename T>", "struct robotModel {", "    T *d_XImats;", "    int *d_topology_helpers;", "};"])
         self.gen_add_code_lines(["template <typename T>", "struct gridData {",

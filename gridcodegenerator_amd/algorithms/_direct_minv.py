@@ -273,7 +273,7 @@ def gen_direct_minv_host(self, mode=0):
     self.gen_add_code_line("const T *d_in = USE_COMPRESSED_MEM ? hd_data->d_q : hd_data->d_q_qd_u;")
     if single_call_timing:
         self.gen_add_code_line("struct timespec start, end; clock_gettime(CLOCK_MONOTONIC,&start);")
-    self.gen_add_code_lines(["hipLaunchKernelGGL((" + kern + "),block_dimms,thread_dimms,MINV_DYNAMIC_SHARED_MEM_COUNT*sizeof(T),0,hd_data->d_Minv,d_in,stride_q,d_robotModel,num_timesteps);",
+    self.gen_add_code_lines(["hipLaunchKernelGGL((" + kern + "),block_dimms,thread_dimms,grid_lds_bytes<T>(thread_dimms),0,hd_data->d_Minv,d_in,stride_q,d_robotModel,num_timesteps);",
                              "gpuErrchk(hipGetLastError()); gpuErrchk(hipDeviceSynchronize());"])
     if single_call_timing:
         self.gen_add_code_line("clock_gettime(CLOCK_MONOTONIC,&end);")

@@ -198,7 +198,7 @@ def gen_forward_dynamics_host(self, mode=0):
     self.gen_add_code_line("// then call the kernel")
     if single_call_timing:
         self.gen_add_code_line("struct timespec start, end; clock_gettime(CLOCK_MONOTONIC,&start);")
-    self.gen_add_code_lines(["hipLaunchKernelGGL((" + kern + "),block_dimms,thread_dimms,FD_DYNAMIC_SHARED_MEM_COUNT*sizeof(T),0,hd_data->d_qdd,hd_data->d_q_qd_u,stride_q_qd_u,d_robotModel,gravity,num_timesteps);",
+    self.gen_add_code_lines(["hipLaunchKernelGGL((" + kern + "),block_dimms,thread_dimms,grid_lds_bytes<T>(thread_dimms),0,hd_data->d_qdd,hd_data->d_q_qd_u,stride_q_qd_u,d_robotModel,gravity,num_timesteps);",
                              "gpuErrchk(hipGetLastError()); gpuErrchk(hipDeviceSynchronize());"])
     if single_call_timing:
         self.gen_add_code_line("clock_gettime(CLOCK_MONOTONIC,&end);")

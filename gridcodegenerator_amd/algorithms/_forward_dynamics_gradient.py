@@ -33,6 +33,24 @@ def gen_forward_dynamics_gradient_inner_python(self, use_thread_group=False, use
     if getattr(self, "branch_frame", False) and stop in (0, 20) and not use_qdd_Minv_input:  # trees of revolute joints: one fused inner, every branch in its tip link's frame
         self.gen_forward_dynamics_gradient_inner_branch_function_call(use_thread_group, s_df_du_name)
         return
+    if getattr(self, "branch_components", False) and stop == 0 and use_qdd_Minv_input:
+        # (qdd, Minv) given: dc/du on the branch-frame path, then this lane's two columns times the caller's M^-1 (dense, read wave-uniformly from LDS)
+        ld = self.minv_ld
+        self.gen_add_code_line("inverse_dynamics_gradient_inner_branch<T>(%s, s_qd, s_qdd, s_X, &s_work[GRID_OFF_SP], d_robotModel, gravity, lane);" % s_df_du_name)
+        self.gen_add_sync(use_thread_group)
+        self.gen_add_code_line("if (lane < %d) {" % n, True)
+        self.gen_add_code_line("T cq[%d], cd[%d];" % (n, n))
+        self.gen_add_code_line("#pragma unroll")
+        self.gen_add_code_line("for (int i = 0; i < %d; i++) { cq[i] = %s[lane*%d + i]; cd[i] = %s[(%d + lane)*%d + i]; }" % (n, s_df_du_name, n, s_df_du_name, n, n))
+        self.gen_add_code_line("#pragma unroll 2")
+        self.gen_add_code_line("for (int row = 0; row < %d; row++) {" % n, True)
+        self.gen_add_code_line("T vq = static_cast<T>(0), vd = static_cast<T>(0);")
+        self.gen_add_code_line("#pragma unroll")
+        self.gen_add_code_line("for (int i = 0; i < %d; i++) { const T mi = s_Minv[row*%d + i]; vq += mi*cq[i]; vd += mi*cd[i]; }" % (n, ld))
+        self.gen_add_code_line("%s[lane*%d + row] = -vq; %s[(%d + lane)*%d + row] = -vd;" % (s_df_du_name, n, s_df_du_name, n, n))
+        self.gen_add_end_control_flow()
+        self.gen_add_end_control_flow()
+        return
     if self.tip_frame and stop in (0, 5, 6, 7, 20):  # serial revolute chains: everything after the X update is one fused inner in the tip link's frame
         self.gen_forward_dynamics_gradient_inner_tip_function_call(use_thread_group, use_qdd_Minv_input, s_df_du_name)
         return
@@ -189,8 +207,8 @@ def gen_forward_dynamics_gradient_host(self, mode=0):
     self.gen_add_code_line("// then call the kernel")
     if single_call_timing:
         self.gen_add_code_line("struct timespec start, end; clock_gettime(CLOCK_MONOTONIC,&start);")
-    self.gen_add_code_lines(["if (USE_QDD_MINV_FLAG) {hipLaunchKernelGGL((" + kern + "),block_dimms,thread_dimms,FD_DU_DYNAMIC_SHARED_MEM_COUNT*sizeof(T),0,hd_data->d_df_du,hd_data->d_q_qd_u,stride_q_qd,hd_data->d_qdd,hd_data->d_Minv,d_robotModel,gravity,num_timesteps);}",
-                             "else {hipLaunchKernelGGL((" + kern + "),block_dimms,thread_dimms,GRID_MAX_SOLVES_PER_BLOCK*(FD_DU_LDS_PER_SOLVE + GRID_OUT_PER_SOLVE)*sizeof(T),0,hd_data->d_df_du,hd_data->d_q_qd_u,stride_q_qd,d_robotModel,gravity,num_timesteps);}",
+    self.gen_add_code_lines(["if (USE_QDD_MINV_FLAG) {hipLaunchKernelGGL((" + kern + "),block_dimms,thread_dimms,grid_lds_bytes<T>(thread_dimms),0,hd_data->d_df_du,hd_data->d_q_qd_u,stride_q_qd,hd_data->d_qdd,hd_data->d_Minv,d_robotModel,gravity,num_timesteps);}",
+                             "else {hipLaunchKernelGGL((" + kern + "),block_dimms,thread_dimms,grid_lds_bytes<T>(thread_dimms, FD_DU_LDS_PER_SOLVE),0,hd_data->d_df_du,hd_data->d_q_qd_u,stride_q_qd,d_robotModel,gravity,num_timesteps);}",
                              "gpuErrchk(hipGetLastError()); gpuErrchk(hipDeviceSynchronize());"])
     if single_call_timing:
         self.gen_add_code_line("clock_gettime(CLOCK_MONOTONIC,&end);")

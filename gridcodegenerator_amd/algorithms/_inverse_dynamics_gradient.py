@@ -440,8 +440,8 @@ def gen_inverse_dynamics_gradient_host(self, mode=0):
     self.gen_add_code_line("const T *d_in = USE_COMPRESSED_MEM ? hd_data->d_q_qd : hd_data->d_q_qd_u;")
     if single_call_timing:
         self.gen_add_code_line("struct timespec start, end; clock_gettime(CLOCK_MONOTONIC,&start);")
-    self.gen_add_code_lines(["if (USE_QDD_FLAG) {hipLaunchKernelGGL((" + kern + "),block_dimms,thread_dimms,ID_DU_DYNAMIC_SHARED_MEM_COUNT*sizeof(T),0,hd_data->d_dc_du,d_in,stride_q_qd,hd_data->d_qdd,d_robotModel,gravity,num_timesteps);}",
-                             "else {hipLaunchKernelGGL((" + kern + "),block_dimms,thread_dimms,ID_DU_DYNAMIC_SHARED_MEM_COUNT*sizeof(T),0,hd_data->d_dc_du,d_in,stride_q_qd,d_robotModel,gravity,num_timesteps);}",
+    self.gen_add_code_lines(["if (USE_QDD_FLAG) {hipLaunchKernelGGL((" + kern + "),block_dimms,thread_dimms,grid_lds_bytes<T>(thread_dimms),0,hd_data->d_dc_du,d_in,stride_q_qd,hd_data->d_qdd,d_robotModel,gravity,num_timesteps);}",
+                             "else {hipLaunchKernelGGL((" + kern + "),block_dimms,thread_dimms,grid_lds_bytes<T>(thread_dimms),0,hd_data->d_dc_du,d_in,stride_q_qd,d_robotModel,gravity,num_timesteps);}",
                              "gpuErrchk(hipGetLastError()); gpuErrchk(hipDeviceSynchronize());"])
     if single_call_timing:
         self.gen_add_code_line("clock_gettime(CLOCK_MONOTONIC,&end);")

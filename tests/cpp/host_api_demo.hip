@@ -1,18 +1,19 @@
 // Exercises the GENERATED C++ host API exactly as a downstream GRiD/MPC program would (reference interface doc block,
 // GRiDCodeGenerator.py:312-380): init_robotModel / init_grid / init_gridData / forward_dynamics_gradient<T> / close_grid,
-// for T = float and T = double.  usage: host_api_demo <in.bin (N x 3n doubles)> <N> <out_f32.bin> <out_f64.bin>
+// for T = float and T = double.  usage: host_api_demo <in.bin (N x 3n doubles)> <N> <out_f32.bin> <out_f64.bin> [threads per block]
 #include "grid.cuh"
 #include <vector>
 
 template <typename T>
-static void run(const std::vector<double> &in, int N, const char *out_path) {
+static void run(const std::vector<double> &in, int N, const char *out_path, int threads) {
     using namespace grid;
     robotModel<T> *d_robotModel = init_robotModel<T>();
     hipStream_t *streams = init_grid<T>();
     gridData<T> *hd_data = init_gridData<T>(N);
     for (size_t i = 0; i < in.size(); i++) hd_data->h_q_qd_u[i] = static_cast<T>(in[i]);
-    const int gpb = SUGGESTED_THREADS / GRID_LANES_PER_SOLVE;
-    dim3 block_dimms((N + gpb - 1) / gpb, 1, 1), thread_dimms(SUGGESTED_THREADS, 1, 1);
+    if (threads <= 0) threads = SUGGESTED_THREADS;
+    const int gpb = threads / GRID_LANES_PER_SOLVE;
+    dim3 block_dimms((N + gpb - 1) / gpb, 1, 1), thread_dimms(threads, 1, 1);
     forward_dynamics_gradient<T>(hd_data, d_robotModel, static_cast<T>(9.81), N, block_dimms, thread_dimms, streams);
     std::vector<double> out((size_t)N * 2 * NUM_JOINTS * NUM_JOINTS);
     for (size_t i = 0; i < out.size(); i++) out[i] = static_cast<double>(hd_data->h_df_du[i]);
@@ -41,7 +42,8 @@ int main(int argc, char **argv) {
     FILE *f = fopen(argv[1], "rb");
     if (!f || fread(in.data(), sizeof(double), in.size(), f) != in.size()) { fprintf(stderr, "bad input\n"); return 2; }
     fclose(f);
-    run<float>(in, N, argv[3]);
-    run<double>(in, N, argv[4]);
+    const int threads = argc > 5 ? atoi(argv[5]) : 0;
+    run<float>(in, N, argv[3], threads);
+    run<double>(in, N, argv[4], threads);
     return 0;
 }

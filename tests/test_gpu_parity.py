@@ -215,7 +215,8 @@ def test_single_timing_probe(torch_cuda, libs, golden):
     assert us > 0
 
 
-def test_generated_host_api_float_and_double(torch_cuda, golden, tmp_path):
+@pytest.mark.parametrize("name,threads", [("hyq", 0), ("atlas", 64), ("tree12", 128)])
+def test_generated_host_api_float_and_double(name, threads, torch_cuda, golden, tmp_path):
     """Downstream-C++ face of the boundary: a program written against the generated header's host API (init_*, forward_dynamics_gradient<T>,
     close_grid) is compiled with hipcc and run for T=float and T=double; the double instantiation must agree with the fp64 oracle goldens
     to rounding level, which pins the generated ALGORITHM independently of fp32 effects."""
@@ -225,18 +226,18 @@ def test_generated_host_api_float_and_double(torch_cuda, golden, tmp_path):
 
     from gridcodegenerator_amd.runtime import HIPCC_FLAGS, generate_header
 
-    g = golden("hyq")
-    n = g["q"].shape[1]
+    g = golden(name)  # (hyq: tip-frame path; atlas, tree12: branch-frame path - in fp64 the formulation itself is pinned to 1e-9;
+    n = g["q"].shape[1]  #  the 30-DoF robot needs blocks of 64 threads in double precision: 8 solves per block would exceed the CU's LDS)
     N = g["q"].shape[0]
     gen_dir = tmp_path / "gen"
-    generate_header(RobotModel.from_fixture("hyq"), str(gen_dir))
+    generate_header(RobotModel.from_fixture(name), str(gen_dir))
     exe = str(tmp_path / "host_api_demo")
     flags = [f for f in HIPCC_FLAGS if f not in ("-shared", "-fPIC")]
     src = os.path.join(os.path.dirname(os.path.abspath(__file__)), "cpp", "host_api_demo.hip")
     subprocess.check_call([shutil.which("hipcc") or "/opt/rocm/bin/hipcc"] + flags + ["-I" + str(gen_dir), src, "-o", exe])
     x = np.hstack([g["q"], g["qd"], g["u"]]).astype(np.float64)
     (tmp_path / "in.bin").write_bytes(x.tobytes())
-    out = subprocess.check_output([exe, str(tmp_path / "in.bin"), str(N), str(tmp_path / "f32.bin"), str(tmp_path / "f64.bin")], text=True)
+    out = subprocess.check_output([exe, str(tmp_path / "in.bin"), str(N), str(tmp_path / "f32.bin"), str(tmp_path / "f64.bin"), str(threads)], text=True)
     assert "float: overload consistency" in out and "double: overload consistency" in out
     ref = np.stack([g["df_du"][k].T.reshape(-1) for k in range(N)])
     f32 = np.frombuffer((tmp_path / "f32.bin").read_bytes(), dtype=np.float64).reshape(N, -1)
