@@ -249,3 +249,69 @@ def test_emulated_fdsva_so(name, libs, golden):
         got = out[k].reshape(4, n, n, n)
         for t in range(4):
             assert np.abs(got[t] - ref[t]).max() <= TOL * max(np.abs(ref[t]).max(), 1e-3), (k, t)
+
+
+def _random_tree_description(seed, n):
+    """A random fixed-base tree of n revolute joints (ids in DFS pre-order, random axes, offsets, inertias); branches stay below 16 joints."""
+    rng = np.random.default_rng(seed)
+    kids_left = {}
+    joints = []
+
+    def grow(parent_link, budget, run):
+        # depth-first: every new joint either continues the current branch, or the parent link gets a further child later
+        while budget[0] > 0:
+            budget[0] -= 1
+            name = "j%d" % len(joints)
+            mass = float(rng.uniform(0.2, 5.0))
+            scale = float(rng.uniform(0.05, 0.3))
+            d = mass * scale ** 2 * rng.uniform(0.05, 0.25, 3)
+            off = 0.1 * float(d.min()) * rng.uniform(-1, 1, 3)
+            joints.append(dict(name=name, type="revolute", axis="xyz"[int(rng.integers(0, 3))], parent_link=parent_link,
+                               xyz=np.round(rng.uniform(-0.3, 0.3, 3), 3).tolist(), rpy=np.round(rng.uniform(-0.6, 0.6, 3), 3).tolist(),
+                               damping=float(rng.choice([0.0, 0.1, 0.3])), limits=[-3.0, 3.0],
+                               link=dict(name=name + "_link", mass=mass, com=np.round(rng.uniform(-0.5, 0.5, 3) * scale, 4).tolist(),
+                                         inertia=[float(d[0]), float(off[0]), float(off[1]), float(d[1]), float(off[2]), float(d[2])])))
+            link = name + "_link"
+            run += 1
+            r = rng.uniform()
+            if r < 0.25 and budget[0] > 1:      # branch point: two or three subtrees hang off this link
+                for _ in range(int(rng.integers(2, 4))):
+                    if budget[0] > 0:
+                        grow(link, budget, 0)
+                return
+            if r < 0.35 or run >= 12:          # leaf
+                return
+            parent_link = link
+
+    budget = [n]
+    while budget[0] > 0:  # several base-rooted components when the first tree ends early
+        grow("base", budget, 0)
+    return dict(name="rnd%d" % seed, base_link="base", joints=joints)
+
+
+@pytest.mark.parametrize("seed,n", [(1, 9), (2, 14), (3, 20), (4, 27)])
+def test_emulated_random_trees_on_the_branch_frame_path(seed, n):
+    """Generator robustness: random tree topologies (nesting depth, component shapes, lane packing all vary) through the unchanged
+    generated header on the branch-frame path, checked against the C oracle (itself pinned by the reference's goldens)."""
+    from gridcodegenerator_amd import GRiDCodeGenerator
+    from oracle.rbd_oracle import Oracle
+
+    robot = RobotModel(_random_tree_description(seed, n))
+    gen = GRiDCodeGenerator(robot)
+    assert gen.branch_frame or gen.tip_frame, "random tree fell back to the column walk"
+    lib = emu_library(robot, max_timesteps=16)
+    rng = np.random.default_rng(100 + seed)
+    N = 5
+    x = np.hstack([rng.uniform(-np.pi, np.pi, (N, n)), rng.uniform(-2, 2, (N, n)), rng.uniform(-10, 10, (N, n))]).astype(np.float32)
+    orc = Oracle(robot)
+    ref, _ = orc.fd_grad_batch(x.astype(np.float64))
+    lib.set_launch_dims(0, 64)
+    assert per_solve_err(lib.forward_dynamics_gradient_host(x), ref) <= TOL
+    if gen.branch_components:
+        qdd = rng.uniform(-5, 5, (N, n)).astype(np.float32)
+        c = np.zeros((N, n), np.float32)
+        lib.inverse_dynamics_device(x, qdd, N, c)
+        assert per_solve_err(c, orc.rnea_batch(x[:, :2 * n].astype(np.float64), qdd.astype(np.float64))) <= TOL
+        dc = np.zeros((N, 2 * n * n), np.float32)
+        lib.inverse_dynamics_gradient_device(x, qdd, N, dc)
+        assert per_solve_err(dc, orc.rnea_grad_batch(x[:, :2 * n].astype(np.float64), qdd.astype(np.float64))) <= TOL

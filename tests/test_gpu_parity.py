@@ -117,13 +117,14 @@ def test_branch_frame_path_grid_stride_and_block_sizes(name, torch_cuda, libs):
     lib.set_launch_dims(0, 0)
 
 
-def test_full_batch_16384_properties(torch_cuda, libs):
-    """BASELINE.json's headline size: size-independent properties instead of a full oracle sweep."""
+@pytest.mark.parametrize("name", ["iiwa14", "atlas"])
+def test_full_batch_16384_properties(name, torch_cuda, libs):
+    """BASELINE.json's headline size (configs 1 and 4: the 7-DoF arm, the 30-DoF humanoid): size-independent properties instead of a full oracle sweep."""
     from oracle.rbd_oracle import Oracle
 
     torch = torch_cuda
-    robot = RobotModel.from_fixture("iiwa14")
-    lib = libs("iiwa14")
+    robot = RobotModel.from_fixture(name)
+    lib = libs(name)
     n, N = robot.n, 16384
     x = inputs(n, N, seed=0)
     out = run_fd_grad(torch, lib, x)
