@@ -24,12 +24,13 @@ A tree has several tips, so every maximal unbranched run of joints (a branch) us
   * M is never inverted: per base-rooted component the tree-sparse U D U^T factorisation (leaves first: no fill-in, Featherstone's
     branch-induced sparsity) is evaluated wave-uniformly in registers, parked in LDS, and every lane solves for its two columns of dc/du.
 
-Scope: fixed-base robots whose joints are all revolute, branches of at most 16 joints that can be packed into the lane group's DPP rows.
-Everything else stays on the column walk; so do the stand-alone component kernels of such robots.
+Scope: fixed-base robots whose joints are all revolute, branches of at most 16 joints that can be packed into the lane group's DPP rows
+(the tree-sparse M and its factors must fit the X(q) storage: 2 * sum(ancestors + 1) + 4 <= 20 n).  Everything else stays on the column walk.
+The stand-alone kernels of such robots (inverse dynamics, its gradient, forward dynamics, M^-1) are subsets of the same emitter
+(_emit_branch_inner(mode)); serial chains of 10 or more joints use the fused inner for forward_dynamics_gradient too (their factors
+live in LDS here, the tip-frame inner replicates a dense factorisation in registers).
 """
 import numpy as np
-
-
 
 
 def gen_branch_frame_plan(self):
