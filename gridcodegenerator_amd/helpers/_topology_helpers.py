@@ -193,6 +193,8 @@ def gen_load_update_XImats_helpers(self, use_thread_group=False):
                              "T *Xo = &s_X[GRID_X_STRIDE*lane];",
                              "const T q = s_q[lane];"])
     types = sorted(set(m.S_index))
+    if len(types) > 1 and any(s_ < 3 for s_ in types):  # one sine/cosine for all revolute lanes instead of one per axis block (the blocks run one after the other)
+        self.gen_add_code_line("T sn, cs; grid_sincos(q, &sn, &cs);")
     first = True
     for s in types:
         ids = [j for j in range(n) if m.S_index[j] == s]
@@ -202,7 +204,8 @@ def gen_load_update_XImats_helpers(self, use_thread_group=False):
         r1, r2 = (a + 1) % 3, (a + 2) % 3
         self.gen_add_code_line(cond + "{ // " + ("revolute" if s < 3 else "prismatic") + " about " + "xyz"[a] + ": joints " + str(ids), True)
         if s < 3:
-            self.gen_add_code_line("T sn, cs; grid_sincos(q, &sn, &cs);")
+            if len(types) == 1:
+                self.gen_add_code_line("T sn, cs; grid_sincos(q, &sn, &cs);")
             self.gen_add_code_line("#pragma unroll")
             self.gen_add_code_line("for (int c = 0; c < 3; c++) {", True)
             for blk in (0, 9):
