@@ -137,7 +137,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    distributed = world > 1
+    distributed = world > 1 or os.environ.get("GRID_BENCH_FORCE_DIST", "0") == "1"  # (FORCE_DIST: tests only - the RCCL code path with a single rank)
     if distributed:
         import torch.distributed as dist
 

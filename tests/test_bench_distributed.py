@@ -65,3 +65,19 @@ def test_two_rank_bench_rehearsal_on_one_gpu():
     assert d["config"]["global_batch"] == 2 * 16384
     assert abs(d["value"] - 2 * 16384 * 100 / (d["ms_per_step"] * 1e-3 * 100)) <= 1e-6 * d["value"]
     assert d["value"] > 1e8
+
+
+@pytest.mark.gpu
+def test_bench_rccl_code_path_with_one_rank():
+    """The production multi-GPU path (backend nccl = RCCL: process-group init bound to the device, GPU barrier, MAX all-reduce of a device
+    tensor) with a single rank under torch.distributed.run - all a one-GPU box can exercise of it (RCCL refuses two ranks on one device)."""
+    port = free_port()
+    env = dict(os.environ, GRID_BENCH_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+                          "--master-port", str(port), os.path.join(REPO, "bench.py"), "--gpus", "1", "--steps", "100", "--warmup", "10", "--no-cpu-baseline"],
+                         env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["value"] > 1e8 and d["scaling"] == "weak"
