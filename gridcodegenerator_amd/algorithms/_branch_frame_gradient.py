@@ -351,10 +351,12 @@ def _emit_branch_inner(self, mode, use_thread_group=False):
     A("grid_wave_sync();")
     if zero is not None:
         A("// zero image of the result (unrelated joints, and rows outside the component of a column, stay exactly zero)")
-        A("for (int e = lane; e < %d; e += %d) {" % ((zero[1] + 3) // 4, lanes), True)
+        A("for (int e = lane; e < %d; e += %d) {" % (zero[1] // 4, lanes), True)
         A("#pragma unroll")
         A("for (int r = 0; r < 4; r++) { %s[4*e + r] = Z; }" % zero[0])
         self.gen_add_end_control_flow()
+        if zero[1] % 4:  # (never past the end of the image: the next lane group's image starts there)
+            A("if (lane < %d) { %s[%d + lane] = Z; }" % (zero[1] % 4, zero[0], zero[1] // 4 * 4))
     # ------------------------------------------------------------------ frame chain along the root path
     TS(1)
     A("//")

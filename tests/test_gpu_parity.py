@@ -460,3 +460,41 @@ def test_generated_host_api_of_a_chain_first_and_second_order_float_and_double(t
                 for t in range(4):
                     a, b = got.reshape(4, -1)[t], ref.reshape(4, -1)[t]
                     assert np.abs(a - b).max() <= tol * max(np.abs(b).max(), 1e-3), (tag, k, t)
+
+
+@pytest.mark.parametrize("seed,n", [(2, 14), (4, 27)])
+def test_random_trees_on_the_gpu(seed, n, torch_cuda, tmp_path):
+    """Generator robustness on the real hardware: random tree topologies (three tree levels, 16- and 32-lane groups, branch hand-over
+    records inside / outside the X(q) storage) are generated, compiled for gfx950 here and checked against the oracle, every kernel."""
+    from oracle.rbd_oracle import Oracle
+    from test_generated_emulation import _random_tree_description
+
+    robot = RobotModel(_random_tree_description(seed, n))
+    lib = GridLibrary(build_library(robot, build_dir=str(tmp_path)), device=0, max_timesteps=2048)
+    try:
+        orc = Oracle(robot)
+        N = 700
+        x = inputs(n, N, seed=seed)
+        ref, _ = orc.fd_grad_batch(x.astype(np.float64))
+        for blocks, threads in [(0, 0), (7, 128)]:
+            lib.set_launch_dims(blocks, threads)
+            assert per_solve_err(run_fd_grad(torch_cuda, lib, x), ref) <= TOL, (blocks, threads)
+        lib.set_launch_dims(0, 0)
+        torch = torch_cuda
+        st = torch.cuda.current_stream().cuda_stream
+        qdd = np.random.default_rng(seed).uniform(-5, 5, (N, n)).astype(np.float32)
+        d_x, d_qdd = torch.from_numpy(x).cuda(), torch.from_numpy(qdd).cuda()
+        d_c = torch.full((N, n), float("nan"), dtype=torch.float32, device="cuda")
+        lib.inverse_dynamics_device(d_x, d_qdd, N, d_c, stream=st)
+        d_dc = torch.full((N, 2 * n * n), float("nan"), dtype=torch.float32, device="cuda")
+        lib.inverse_dynamics_gradient_device(d_x, d_qdd, N, d_dc, stream=st)
+        d_acc = torch.full((N, n), float("nan"), dtype=torch.float32, device="cuda")
+        lib.forward_dynamics_device(d_x, N, d_acc, stream=st)
+        torch.cuda.synchronize()
+        x64 = x.astype(np.float64)
+        assert per_solve_err(d_c.cpu().numpy(), orc.rnea_batch(x64[:, :2 * n], qdd.astype(np.float64))) <= TOL
+        assert per_solve_err(d_dc.cpu().numpy(), orc.rnea_grad_batch(x64[:, :2 * n], qdd.astype(np.float64))) <= TOL
+        qdd_ref = np.stack([orc.fd_grad(x64[k, :n], x64[k, n:2 * n], x64[k, 2 * n:], full=True)[1] for k in range(64)])
+        assert per_solve_err(d_acc.cpu().numpy()[:64], qdd_ref) <= TOL
+    finally:
+        lib.close()
