@@ -305,8 +305,10 @@ def test_emulated_random_trees_on_the_branch_frame_path(seed, n):
     x = np.hstack([rng.uniform(-np.pi, np.pi, (N, n)), rng.uniform(-2, 2, (N, n)), rng.uniform(-10, 10, (N, n))]).astype(np.float32)
     orc = Oracle(robot)
     ref, _ = orc.fd_grad_batch(x.astype(np.float64))
+    for blocks, threads in [(0, 64), (1, 128)]:  # one wave per block, and several waves sharing the block's LDS (with a grid-stride loop)
+        lib.set_launch_dims(blocks, threads)
+        assert per_solve_err(lib.forward_dynamics_gradient_host(x), ref) <= TOL, (blocks, threads)
     lib.set_launch_dims(0, 64)
-    assert per_solve_err(lib.forward_dynamics_gradient_host(x), ref) <= TOL
     if gen.branch_components:
         qdd = rng.uniform(-5, 5, (N, n)).astype(np.float32)
         c = np.zeros((N, n), np.float32)
