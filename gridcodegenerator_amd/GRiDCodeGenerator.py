@@ -104,6 +104,10 @@ class GRiDCodeGenerator:
         # solves) where the branch-frame inner keeps its factors in LDS (46 us); measured the other way round for 8 joints (18 vs 13 us).
         want_branch = mode == "branch" or (mode == "auto" and (not self.tip_frame or self.tip_L >= 10))
         self.branch_plan = self.gen_branch_frame_plan() if (COLS_PER_LANE == 2 and not DEBUG_MODE and want_branch) else None
+        if mode == "auto" and self.branch_plan is not None and self.branch_plan["factor_work"] > 1000:
+            # every lane factors its whole component: beyond ~1000 multiply-adds (a dense 18-joint chain) that costs more than it saves
+            # (20-joint chain, 4 096 solves: 99 us against 90 us on the column walk; 27-joint random tree with 651: 141 against 154 us)
+            self.branch_plan = None
         if mode == "branch" and self.branch_plan is None:
             raise NotImplementedError("GRID_GRADIENT_WALK=branch needs revolute joints and branches that fit the 16-lane rows of the lane group")
         self.branch_frame = self.branch_plan is not None

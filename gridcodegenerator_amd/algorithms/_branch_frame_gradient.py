@@ -44,9 +44,10 @@ def gen_branch_frame_plan(self):
     ch = [list(m.children[j]) for j in range(n)]
     br = [-1] * n
     branches = []
+    rowcap = min(16, lanes)
     for j in range(n):
         p = parent[j]
-        if p < 0 or len(ch[p]) >= 2:
+        if p < 0 or len(ch[p]) >= 2 or len(branches[br[p]]) >= rowcap:  # (a run longer than a DPP row continues as a child branch: a junction with one child)
             br[j] = len(branches)
             branches.append([j])
         else:
@@ -67,9 +68,6 @@ def gen_branch_frame_plan(self):
             path.append(j)
             j = parent[j]
         paths.append(path)
-    rowcap = min(16, lanes)
-    if max(len(J) for J in branches) > rowcap:
-        return None
     rows = [[] for _ in range(lanes // rowcap)]
     for b in sorted(range(nb), key=lambda b_: (-len(branches[b_]), b_)):  # first-fit decreasing
         for r in rows:
@@ -107,13 +105,23 @@ def gen_branch_frame_plan(self):
         mstart[j] = at
         at += len(m.ancestors[j]) + 1
     ubase = {cb: mstart[cb] for cb in comps}
+    # multiply-adds of the (replicated) factorisation of the largest component: the price of keeping it wave-uniform
+    factor_work = max(sum(len(m.ancestors[cb + i]) * (len(m.ancestors[cb + i]) + 1) // 2 for i in range(len(m.subtree[cb]))) for cb in comps)
     nnz = at
-    if 2 * nnz + 4 > 20 * n:
-        return None  # (M and its factors live in the X(q) storage once the frames are known)
-    g_in_x = 2 * nnz + 28 * nb + 4 <= 20 * n  # the branch hand-over records too when they fit; else behind the path axes
+    # LDS placement: once the frames are known the X(q) storage (20 n values) is re-used for M (must fit, with one spare quad for the
+    # branch-free stores), then for the factors and the branch hand-over records as far as they fit; what does not goes behind the path axes
+    if nnz + 4 > 20 * n:
+        return None
+    place, x_at, sp_at = {"M": ("x", 0), "trash": ("x", nnz)}, nnz + 4, 6 * D * (nb + 1)
+    for item, size in (("U", nnz), ("G", 28 * nb)):
+        if x_at + size <= 20 * n:
+            place[item] = ("x", x_at)
+            x_at += size
+        else:
+            place[item] = ("sp", sp_at)
+            sp_at += size
     return dict(branches=branches, br=br, pb=pb, level=level, paths=paths, joint_of_lane=joint_of_lane, kids=kids, comp_base=comp_base,
-                shapes=shapes, shape_of=shape_of, D=D, maxLb=max(len(J) for J in branches), maxlevel=max(level), maxchild=maxchild, row_len=row_len, nb=nb, ubase=ubase, mstart=mstart, nnz=nnz, g_in_x=g_in_x,
-                sp_size=6 * D * (nb + 1) + (0 if g_in_x else 28 * nb))
+                shapes=shapes, shape_of=shape_of, D=D, maxLb=max(len(J) for J in branches), maxlevel=max(level), maxchild=maxchild, row_len=row_len, nb=nb, ubase=ubase, mstart=mstart, nnz=nnz, place=place, sp_size=sp_at, factor_work=factor_work)
 
 
 def gen_branch_frame_constants(self):
@@ -309,7 +317,7 @@ def _emit_branch_inner(self, mode, use_thread_group=False):
                            "the caller must grid_wave_sync() before other lanes read the result"],
                           ["s_X is this solve's compact X(q) storage (the rotation blocks are read; once the frames are known it is re-used for the",
                            "     tree-sparse M, its factors and the branch hand-over records)",
-                           "s_SP is LDS scratch for the joint axes along the root path of every branch (6 values per path joint, plus one spare record per solve%s)" % ("" if P["g_in_x"] else "; then the branch hand-over records"),
+                           "s_SP is LDS scratch for the joint axes along the root path of every branch (6 values per path joint, plus one spare record per solve%s)" % ("" if all(v[0] == "x" for v in P["place"].values()) else "; then what does not fit into s_X: " + ", ".join(k for k, v in P["place"].items() if v[0] == "sp")),
                            "d_robotModel is the pointer to the initialized model specific helpers on the GPU",
                            "lane is the caller's lane index inside the solve's lane group"], None)
     A("template <typename T>")
@@ -336,10 +344,8 @@ def _emit_branch_inner(self, mode, use_thread_group=False):
     A("const int cbase = static_cast<int>(d_L[17]), shape = static_cast<int>(d_L[18]), plen = static_cast<int>(d_L[19]), ubase = static_cast<int>(d_L[20]), mstart = static_cast<int>(d_L[21]);")
     for c in range(maxchild):
         A("const int cs%d = static_cast<int>(d_L[%d]); // child branch %d of this lane's branch (-1: none)" % (c, H + D + c, c))
-    if P["g_in_x"]:
-        A("T *s_Mc = &s_X[0], *s_Uc = &s_X[%d + ubase], *s_G = &s_X[%d], *s_trash = &s_X[%d]; // (valid once the frame chain is done with X(q))" % (P["nnz"], 2 * P["nnz"], 2 * P["nnz"] + 28 * P["nb"]))
-    else:
-        A("T *s_Mc = &s_X[0], *s_Uc = &s_X[%d + ubase], *s_G = &s_SP[%d], *s_trash = &s_X[%d]; // (s_X: valid once the frame chain is done with X(q))" % (P["nnz"], 6 * D * (P["nb"] + 1), 2 * P["nnz"]))
+    ptr = lambda item: "&s_%s[%d]" % ("X" if P["place"][item][0] == "x" else "SP", P["place"][item][1])
+    A("T *s_Mc = %s, *s_Uc = %s + ubase, *s_G = %s, *s_trash = %s; // (s_X: valid once the frame chain is done with X(q))" % (ptr("M"), ptr("U"), ptr("G"), ptr("trash")))
     A("const int own = Lb - 1 - pos; // index of this lane's joint on the root path of its branch (tip -> root); -1 on lanes without a joint")
     A("const int li = jid - cbase;   // index of the joint inside its base-rooted component")
     A("T *s_Sp = &s_SP[%d*slot]; // joint axes along the root path of this lane's branch, in the branch frame" % (6 * D))

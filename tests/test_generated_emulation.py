@@ -317,3 +317,29 @@ def test_emulated_random_trees_on_the_branch_frame_path(seed, n):
         dc = np.zeros((N, 2 * n * n), np.float32)
         lib.inverse_dynamics_gradient_device(x, qdd, N, dc)
         assert per_solve_err(dc, orc.rnea_grad_batch(x[:, :2 * n].astype(np.float64), qdd.astype(np.float64))) <= TOL
+
+
+def test_emulated_run_longer_than_a_dpp_row_is_split_into_branches():
+    """A 20-joint chain does not fit one 16-lane DPP row: the branch-frame plan continues it as a child branch (a junction with one child) and
+    the factors no longer fit the X(q) storage (they go behind the path axes).  auto mode leaves such a robot on the column walk (the
+    replicated factorisation of a dense 20-joint chain costs more than it saves); GRID_GRADIENT_WALK=branch forces the path."""
+    from gridcodegenerator_amd import GRiDCodeGenerator
+    from gridcodegenerator_amd.fixtures.make_fixtures import chain12
+    from oracle.rbd_oracle import Oracle
+    import os
+
+    robot = RobotModel(chain12(20, 77, "chain20"))
+    assert not GRiDCodeGenerator(robot).branch_frame
+    os.environ["GRID_GRADIENT_WALK"] = "branch"
+    try:
+        plan = GRiDCodeGenerator(robot).branch_plan
+    finally:
+        del os.environ["GRID_GRADIENT_WALK"]
+    assert [len(b) for b in plan["branches"]] == [16, 4] and plan["level"] == [0, 1] and plan["place"]["U"][0] == "sp" and plan["factor_work"] == 1330
+    lib = emu_library(robot, max_timesteps=8, env={"GRID_GRADIENT_WALK": "branch"})
+    n, N = 20, 3
+    rng = np.random.default_rng(0)
+    x = np.hstack([rng.uniform(-np.pi, np.pi, (N, n)), rng.uniform(-2, 2, (N, n)), rng.uniform(-10, 10, (N, n))]).astype(np.float32)
+    ref, _ = Oracle(robot).fd_grad_batch(x.astype(np.float64))
+    lib.set_launch_dims(0, 64)
+    assert per_solve_err(lib.forward_dynamics_gradient_host(x), ref) <= TOL

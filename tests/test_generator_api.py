@@ -98,7 +98,7 @@ def test_formulation_chosen_per_robot():
         g = GRiDCodeGenerator(RobotModel.from_fixture(name))
         assert (g.tip_frame, g.branch_frame, g.branch_components) == want, name
     plan = GRiDCodeGenerator(RobotModel.from_fixture("tree12")).branch_plan
-    assert plan["maxlevel"] == 2 and len(plan["shapes"]) == 2 and plan["nb"] == 6 and not plan["g_in_x"]
+    assert plan["maxlevel"] == 2 and len(plan["shapes"]) == 2 and plan["nb"] == 6 and plan["place"]["G"][0] == "sp" and plan["place"]["U"][0] == "x"
     plan = GRiDCodeGenerator(RobotModel.from_fixture("atlas")).branch_plan
     assert plan["maxlevel"] == 1 and plan["D"] == 10 and plan["nnz"] == 150 and sorted(j for j in plan["joint_of_lane"] if j >= 0) == list(range(30))
     # every branch sits inside one 16-lane row
