@@ -289,7 +289,7 @@ def _random_tree_description(seed, n):
     return dict(name="rnd%d" % seed, base_link="base", joints=joints)
 
 
-@pytest.mark.parametrize("seed,n", [(1, 9), (2, 14), (3, 20), (4, 27)])
+@pytest.mark.parametrize("seed,n", [(16, 8), (13, 7), (1, 9), (2, 14), (3, 20), (4, 27)])  # (8-lane groups with two tree levels / two components, ..., 32-lane groups)
 def test_emulated_random_trees_on_the_branch_frame_path(seed, n):
     """Generator robustness: random tree topologies (nesting depth, component shapes, lane packing all vary) through the unchanged
     generated header on the branch-frame path, checked against the C oracle (itself pinned by the reference's goldens)."""
