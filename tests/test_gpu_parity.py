@@ -89,7 +89,7 @@ def test_host_entry_point_and_grid_stride(torch_cuda, libs):
     ref, _ = Oracle(robot).fd_grad_batch(x.astype(np.float64))
     out = lib.forward_dynamics_gradient_host(x)
     assert per_solve_err(out, ref) <= TOL
-    for blocks, threads in [(3, 256), (7, 64), (5, 96), (2, 512)]:  # fewer blocks than batches -> grid-stride; ragged block sizes
+    for blocks, threads in [(3, 256), (7, 64), (5, 96), (2, 512), (9, 40), (4, 24), (64, 8), (1, 504), (0, 200)]:  # fewer blocks than batches -> grid-stride; ragged block sizes (partial last waves)
         lib.set_launch_dims(blocks, threads)
         out = lib.forward_dynamics_gradient_host(x)
         assert per_solve_err(out, ref) <= TOL, (blocks, threads)
