@@ -98,7 +98,7 @@ def gen_branch_frame_plan(self):
         shape_of[cb] = shapes.index(sig)
     D = max(len(p_) for p_ in paths)
     maxchild = max([len(k_) for k_ in kids] + [0])
-    row_len = (24 + D + max(maxchild, 1) + 3) // 4 * 4
+    row_len = (24 + D + max(maxchild, 1) + 3 * D + 3) // 4 * 4  # (header | path codes | child branches | joint offsets along the path)
     # compact (tree-sparse) storage of M and of its factors: column k holds the entries of its ancestors (ascending) and then the diagonal
     mstart, at = [0] * n, 0
     for j in range(n):
@@ -127,7 +127,8 @@ def gen_branch_frame_plan(self):
 def gen_branch_frame_constants(self):
     """Table rows appended to grid_model_constants: one row per lane
     [Ic (6) | c (3) | m | damping | axis | joint id | pos | branch length | level | branch slot | component base | shape | path length | factor base of the component | start of the joint's column in the compact M | 2 spare |
-     path codes (4*joint + axis, tip -> root, -1 = none) x D | child branch slots (-1 = none) x maxchild], then 4 floats per joint: the joint offset."""
+     path codes (4*joint + axis, tip -> root, -1 = none) x D | child branch slots (-1 = none) x maxchild |
+     origin of every path joint's frame in its parent's coordinates x D (so that no table read depends on another one)]."""
     m = self.model
     P = self.branch_plan
     rows = []
@@ -161,10 +162,11 @@ def gen_branch_frame_constants(self):
             row[24 + i] = float(4 * path[i] + m.S_index[path[i]]) if i < len(path) else -1.0
         for c_ in range(max(P["maxchild"], 1)):
             row[24 + P["D"] + c_] = float(P["kids"][b][c_]) if c_ < len(P["kids"][b]) else -1.0
+        ro = 24 + P["D"] + max(P["maxchild"], 1)
+        for i, pj in enumerate(P["paths"][b]):
+            r = self.gen_tip_frame_joint_offset(pj)
+            row[ro + 3 * i:ro + 3 * i + 3] = [float(r[0]), float(r[1]), float(r[2])]
         rows += row
-    for j in range(m.n):
-        r = self.gen_tip_frame_joint_offset(j)
-        rows += [r[0], r[1], r[2], 0.0]
     return rows
 
 
@@ -304,7 +306,6 @@ def _emit_branch_inner(self, mode, use_thread_group=False):
     lanes = self.lanes_per_solve
     ld = self.minv_ld
     tab = self.branch_tab_offset
-    roff = tab + RL * lanes
     H = 24
     A = self.gen_add_code_line
     outdoc = {"fdgrad": "s_df_du receives -Minv*dc/du in the device layout [col*n + row] (2*NUM_JOINTS*NUM_JOINTS values; also the assembly area of dc/du)",
@@ -370,9 +371,10 @@ def _emit_branch_inner(self, mode, use_thread_group=False):
     A("//")
     A("T myR[9], myp[3], TR[9], Tp[3], gvec[3] = {Z, Z, Z};")
     A("{", True)
+    ro = H + D + max(maxchild, 1)
     A("T rj[%d][3]; // origins of the path joints' frames in their parents' coordinates: all table reads issued before the first use" % D)
     for i in range(D - 1):
-        A("{ const T *d_r = &grid_model_constants(static_cast<const T *>(nullptr))[%d + 4*pj%d]; rj[%d][0] = d_r[0]; rj[%d][1] = d_r[1]; rj[%d][2] = d_r[2]; }" % (roff, i, i, i, i))
+        A("rj[%d][0] = d_L[%d]; rj[%d][1] = d_L[%d]; rj[%d][2] = d_L[%d];" % (i, ro + 3 * i, i, ro + 3 * i + 1, i, ro + 3 * i + 2))
     A("T Rc[9] = {static_cast<T>(1), Z, Z, Z, static_cast<T>(1), Z, Z, Z, static_cast<T>(1)};")
     A("T pc[3] = {Z, Z, Z};")
     A("#pragma unroll")
