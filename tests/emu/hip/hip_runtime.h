@@ -67,7 +67,7 @@ void launch(dim3 grid, dim3 block, size_t smem_bytes, F &&body) {
         for (unsigned bx = 0; bx < grid.x; bx++) {
             // LDS contents are undefined at block start on the hardware: poison them (NaN pattern) so that a read-before-write, or a
             // hand-off that only works because a previous block left the same values behind, shows up as NaN instead of passing by luck
-            for (size_t w = 0; w + 4 <= sizeof(grid_smem_raw); w += 4) { const unsigned poison = 0x7fc0dead; memcpy(grid_smem_raw + w, &poison, 4); }
+            for (size_t w = 0; w + 4 <= smem_bytes; w += 4) { const unsigned poison = 0x7fc0dead; memcpy(grid_smem_raw + w, &poison, 4); }  // (the block's own allocation)
             std::barrier<> bar(nthreads);
             g_barrier = &bar;
             std::vector<std::thread> ts;

@@ -30,7 +30,7 @@ def emu_library(robot, max_timesteps=64, cols_per_lane=None, env=None):
                 else:
                     os.environ[k] = v
         so = os.path.join(out_dir, "libgrid_emu_%s.so" % key)
-        cmd = ["g++", "-std=c++20", "-O1", "-g0", "-x", "c++", "-shared", "-fPIC", "-pthread", "-I" + EMU_INC, "-I" + out_dir, "-I" + INCLUDE_DIR,
+        cmd = ["g++", "-std=c++20", "-O0", "-g0", "-x", "c++", "-shared", "-fPIC", "-pthread", "-I" + EMU_INC, "-I" + out_dir, "-I" + INCLUDE_DIR,
                '-DGRID_ROBOT_NAME="%s"' % robot.name, "-Wno-unused-value", CAPI_SRC, "-o", so]
         subprocess.check_call(cmd)
         _CACHE[key] = so
