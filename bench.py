@@ -1,13 +1,21 @@
 #!/usr/bin/env python3
-"""Headline benchmark: forward_dynamics_gradient solves/sec, iiwa-14, batch 16384 per GPU (BASELINE.json metric).
+"""Headline benchmark: forward_dynamics_gradient solves/sec, iiwa-14, batch 16384 (BASELINE.json metric).
 
     python bench.py --gpus 1 --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
-One "step" = one pass of the hot path (one forward_dynamics_gradient_kernel launch through the C ABI) over one batch of
-16384 synthetic solves whose inputs and outputs are resident in HBM.  Every rank owns its own batch (the batch axis shards
-with no collective: "scaling": "weak"); value = solves processed by all ranks / max-over-ranks wall time of the K steps.
-Rank 0 prints ONE JSON line.
+One "step" = one pass of the hot path (one forward_dynamics_gradient_kernel launch through the C ABI) over the job's batch of
+synthetic solves whose inputs and outputs are resident in HBM.
+
+Multi-GPU: the batch axis shards with no collective.
+  --scaling strong (default): ONE global batch of 16384 solves, rank r owns the contiguous range [r*B/G, (r+1)*B/G) of it;
+  --scaling weak: every rank owns its own 16384-solve batch.  With N > 1 the line also carries the other mode as a second key.
+value = solves processed by all ranks / max-over-ranks wall time of the K steps.  Rank 0 prints ONE JSON line.
+
+Protocol of the timed region: `--warmup` untimed steps, barrier + synchronize, EXACTLY `--steps` launches bracketed by one HIP event
+pair on the launch stream, synchronize, barrier.  Before the warm-up steps a DISCLOSED, untimed clock warm ("clock_warm_ms") keeps the
+GPU busy so that a short run is not timed on a clock still ramping up from idle.  A second, diagnostic pass of K launches with one
+event per launch gives the per-launch distribution ("launch_us_median"); it is not part of `value`.
 """
 import argparse
 import json
@@ -25,7 +33,10 @@ ROBOT = "iiwa14"
 BATCH = 16384
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec); ~6.3 TB/s measured copy ceiling
 FP32_PEAK_TFLOPS = 157.3       # MI355X_MICROARCH.md: peak FP32 vector
-FLOPS_PER_SOLVE = 53e3         # static estimate of the reference's emitted code, n = 7
+FLOPS_PER_SOLVE_REFERENCE = 53e3   # static estimate of the REFERENCE's emitted code, n = 7 (not what this kernel executes)
+N_SIMDS = 1024                 # 256 CUs x 4 SIMDs
+CLOCK_GHZ = 2.4                # MI355X_MICROARCH.md: max clock
+PMC_FILE = os.path.join("profiles", "pmc_counters.json")   # per-launch counters of the headline kernel from committed rocprofv3 --pmc passes
 
 
 def make_inputs(n, N, seed=0):
@@ -34,9 +45,36 @@ def make_inputs(n, N, seed=0):
     return np.hstack([rng.uniform(-np.pi, np.pi, (N, n)), rng.uniform(-2, 2, (N, n)), rng.uniform(-10, 10, (N, n))]).astype(np.float32)
 
 
-def cpu_baseline(robot, x, budget_s=12.0):
-    """Times the CPU oracle (fp32 build of oracle/rbd_oracle.c, the restatement of the reference's NumPy oracle) on this
-    host's cores: the checker used as a reported baseline, never as part of the measured GPU path."""
+def shard_range(N, world, rank):
+    """Strong scaling: contiguous range [k0, k1) of the global batch owned by `rank` (same arithmetic as csrc/grid_capi.hip: multi_range)."""
+    per = (N + world - 1) // world
+    return min(rank * per, N), min((rank + 1) * per, N)
+
+
+def rank_inputs(n, N, world, rank, scaling):
+    """This rank's synthetic shard.  strong: its slice of the ONE global seeded batch; weak: its own batch (seed = rank)."""
+    if scaling == "strong":
+        k0, k1 = shard_range(N, world, rank)
+        return make_inputs(n, N, seed=0)[k0:k1]
+    return make_inputs(n, N, seed=rank)
+
+
+def _timed_rate(fn, nsolves, budget_s, max_reps=100000):
+    reps = 0
+    t0 = time.perf_counter()
+    while True:
+        fn()
+        reps += 1
+        dt = time.perf_counter() - t0
+        if dt >= budget_s or reps >= max_reps:
+            break
+    return reps * nsolves / dt, reps, dt
+
+
+def cpu_baseline(robot, x, budget_s=10.0):
+    """Times the CPU oracle (oracle/rbd_oracle.c, the C restatement of the reference's NumPy oracle) on this host's cores: the checker
+    used as a reported baseline, never as part of the measured GPU path.  ~20 s of CPU work in total: thread-count sweep, the all-cores
+    fp32 sample, and single-thread fp32 / fp64 samples."""
     from oracle import rbd_oracle
 
     so = None
@@ -45,6 +83,7 @@ def cpu_baseline(robot, x, budget_s=12.0):
     except Exception:
         so = None
     orc = rbd_oracle.Oracle(robot, dtype=np.float32, lib_path=so)
+    orc64 = rbd_oracle.Oracle(robot, dtype=np.float64, lib_path=so)
     sample = x  # the whole bench batch per call (enough work per thread for the static OpenMP split)
     # the job may own fewer CPUs than the host shows (a 1-GPU box gets a share of the host): pick the thread count that is
     # actually fastest from a short sweep, then time the bounded sample with it; `cores` reports the threads used
@@ -52,30 +91,18 @@ def cpu_baseline(robot, x, budget_s=12.0):
     best_nt, best_rate = 1, 0.0
     for nt in sorted(set(min(avail, c) for c in (4, 8, 16, 32, 64, 128, avail))):
         orc.fd_grad_batch(sample, nthreads=nt)
-        t0 = time.perf_counter()
-        k = 0
-        while time.perf_counter() - t0 < 0.4:
-            orc.fd_grad_batch(sample, nthreads=nt)
-            k += 1
-        rate = k / (time.perf_counter() - t0)
+        rate, _, _ = _timed_rate(lambda: orc.fd_grad_batch(sample, nthreads=nt), 1, 0.4)
         if rate > best_rate:
             best_nt, best_rate = nt, rate
     cores = best_nt
-    reps = 0
-    t0 = time.perf_counter()
-    while True:  # time-bounded sample (~budget_s of CPU work), whatever the host's load
-        orc.fd_grad_batch(sample, nthreads=cores)
-        reps += 1
-        dt = time.perf_counter() - t0
-        if dt >= budget_s or reps >= 20000:
-            break
-    return {"value": reps * sample.shape[0] / dt, "unit": "solves/s", "cores": int(cores), "kind": "port",
-            "sample": "%d x %d iiwa14 solves of the bench batch, fp32 C oracle (oracle/rbd_oracle.c, -O3 -march=native, OpenMP static, best of a thread-count sweep on %d visible CPUs), %.1f s" % (reps, sample.shape[0], avail, dt)}
-
-
-def shard_seed(rank):
-    """Every rank owns its own batch: rank r generates shard r of the job's synthetic input (no data-path collective)."""
-    return rank
+    value, reps, dt = _timed_rate(lambda: orc.fd_grad_batch(sample, nthreads=cores), sample.shape[0], budget_s)
+    small = sample[:2048]
+    small64 = small.astype(np.float64)
+    r32, _, _ = _timed_rate(lambda: orc.fd_grad_batch(small, nthreads=1), small.shape[0], 2.0)
+    r64, _, _ = _timed_rate(lambda: orc64.fd_grad_batch(small64, nthreads=1), small.shape[0], 2.0)
+    return {"value": value, "unit": "solves/s", "cores": int(cores), "kind": "port",
+            "sample": "%d x %d iiwa14 solves of the bench batch, fp32 C oracle (oracle/rbd_oracle.c, -O3 -march=native, OpenMP static, best of a thread-count sweep on %d visible CPUs), %.1f s" % (reps, sample.shape[0], avail, dt),
+            "single_thread_fp32": r32, "single_thread_fp64": r64, "single_thread_sample": "2048 solves per call, 2 s each"}
 
 
 def reduce_max(elapsed, dist, device):
@@ -87,7 +114,8 @@ def reduce_max(elapsed, dist, device):
 
 
 def harness_selftest(args):
-    """Multi-rank plumbing only (gloo, CPU): no kernels, no metric."""
+    """Multi-rank plumbing only (gloo, CPU): no kernels, no metric.  Checks that the ranks' shards are what the scaling mode defines:
+    strong -> the concatenation of the ranks' slices IS the one global batch; weak -> pairwise distinct batches."""
     import torch
     import torch.distributed as dist
 
@@ -95,20 +123,47 @@ def harness_selftest(args):
     rank = int(os.environ.get("RANK", "0"))
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     dist.init_process_group(backend="gloo")
-    x = make_inputs(7, 64, seed=shard_seed(rank))
-    checksum = torch.tensor([float(np.abs(x).sum())], dtype=torch.float64)
-    sums = [torch.zeros(1, dtype=torch.float64) for _ in range(world)]
-    dist.all_gather(sums, checksum)
+    n, N = 7, args.batch
+    x = rank_inputs(n, N, world, rank, args.scaling)
+    k0, k1 = shard_range(N, world, rank) if args.scaling == "strong" else (0, N)
+    info = torch.tensor([float(k0), float(k1), float(x.shape[0]), float(np.abs(x.astype(np.float64)).sum())], dtype=torch.float64)
+    infos = [torch.zeros(4, dtype=torch.float64) for _ in range(world)]
+    dist.all_gather(infos, info)
     dist.barrier()
     t0 = time.perf_counter()
     time.sleep(0.01 * (rank + 1))  # rank-dependent "work": the reported time must be the slowest rank's
     elapsed = reduce_max(time.perf_counter() - t0, dist, torch.device("cpu"))
     dist.barrier()
     if rank == 0:
-        print(json.dumps({"selftest": "bench harness", "n_gpus": world, "max_elapsed_s": elapsed,
-                          "distinct_shards": len(set(round(float(s.item()), 6) for s in sums)) == world,
-                          "solves_counted": world * args.batch * args.steps}))
+        ranges = [(int(i[0]), int(i[1])) for i in infos]
+        total_checksum = float(sum(i[3] for i in infos))
+        global_checksum = float(np.abs(make_inputs(n, N, seed=0).astype(np.float64)).sum())
+        print(json.dumps({"selftest": "bench harness", "n_gpus": world, "scaling": args.scaling, "max_elapsed_s": elapsed,
+                          "ranges": ranges, "rows": [int(i[2]) for i in infos],
+                          "contiguous_cover": args.scaling == "strong" and ranges[0][0] == 0 and ranges[-1][1] == N and all(ranges[i][1] == ranges[i + 1][0] for i in range(world - 1)),
+                          "shards_sum_to_global_batch": abs(total_checksum - global_checksum) <= 1e-9 * global_checksum,
+                          "distinct_shards": len(set(round(float(i[3]), 6) for i in infos)) == world,
+                          "solves_counted": (N if args.scaling == "strong" else world * N) * args.steps}))
     dist.destroy_process_group()
+
+
+def measured_copy_bandwidth(torch, dev):
+    """HBM bandwidth a plain device-to-device copy reaches on this GPU (read + write bytes / time): the measured ceiling next to the 8 TB/s spec."""
+    nbytes = 1 << 30
+    a = torch.empty(nbytes // 4, dtype=torch.float32, device=dev)
+    b = torch.empty_like(a)
+    for _ in range(3):
+        b.copy_(a)
+    torch.cuda.synchronize(dev)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    reps = 10
+    for _ in range(reps):
+        b.copy_(a)
+    e1.record()
+    torch.cuda.synchronize(dev)
+    del a, b
+    return 2.0 * nbytes * reps / (e0.elapsed_time(e1) * 1e-3) / 1e9
 
 
 def main():
@@ -116,12 +171,17 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1000)
     ap.add_argument("--warmup", type=int, default=50)
-    ap.add_argument("--batch", type=int, default=BATCH, help="solves per GPU per step")
+    ap.add_argument("--batch", type=int, default=BATCH, help="global batch (strong scaling) / solves per GPU (weak scaling) per step")
+    ap.add_argument("--scaling", choices=("strong", "weak"), default="strong",
+                    help="strong (default): one global batch of --batch solves cut into contiguous per-GPU ranges; weak: --batch solves per GPU")
+    ap.add_argument("--clock-warm-ms", type=float, default=50.0, help="untimed, disclosed GPU clock warm before the warm-up steps (0 = off)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the copy-bandwidth, end-to-end and second-scaling-mode measurements")
     ap.add_argument("--threads", type=int, default=0, help="threads per block override (0 = library default)")
     ap.add_argument("--blocks", type=int, default=0, help="blocks override (0 = one lane-group batch per block)")
     ap.add_argument("--build-dir", default=None, help="load the robot library from another build directory (tuning experiments)")
     ap.add_argument("--no-parity", action="store_true", help="skip the oracle spot check (timing ablation builds produce wrong results on purpose)")
+    ap.add_argument("--dump", default=None, help="directory: every rank saves its output shard as out_rank<r>.npy (tests: the shards of a strong-scaling job concatenate to the 1-rank result)")
     ap.add_argument("--harness-selftest", action="store_true",
                     help="CPU-only check of the multi-rank harness (gloo rendezvous, sharding, barrier, MAX-reduce, single JSON line); "
                          "runs NO dynamics and reports NO metric - used by tests/test_bench_distributed.py")
@@ -138,6 +198,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     distributed = world > 1 or os.environ.get("GRID_BENCH_FORCE_DIST", "0") == "1"  # (FORCE_DIST: tests only - the RCCL code path with a single rank)
+    rehearsal = False
     if distributed:
         import torch.distributed as dist
 
@@ -157,17 +218,11 @@ def main():
 
     robot = RobotModel.from_fixture(ROBOT)
     n = robot.n
-    N = args.batch
-    lib = load(ROBOT, device=local_rank, max_timesteps=N, build_dir=args.build_dir)  # raises if the HIP library is missing (no CPU fallback)
+    B = args.batch
+    lib = load(ROBOT, device=local_rank, max_timesteps=B, build_dir=args.build_dir)  # raises if the HIP library is missing (no CPU fallback)
     if args.threads or args.blocks:
         lib.set_launch_dims(args.blocks, args.threads)
-    x = make_inputs(n, N, seed=shard_seed(rank))  # every rank owns a different shard of the job
-    d_in = torch.from_numpy(x).to(dev)
-    d_out = torch.empty((N, 2 * n * n), dtype=torch.float32, device=dev)
     stream = torch.cuda.current_stream(dev)
-
-    def step():
-        lib.forward_dynamics_gradient_device(d_in, N, d_out, stream=stream.cuda_stream)
 
     def barrier():
         torch.cuda.synchronize(dev)
@@ -175,63 +230,126 @@ def main():
             dist.barrier()
             torch.cuda.synchronize(dev)
 
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    # ---- timed region: exactly K steps; HIP events on the launch stream bracket it for the per-launch kernel time
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    ev0.record(stream)
-    for _ in range(args.steps):
-        step()
-    ev1.record(stream)
-    torch.cuda.synchronize(dev)                 # this rank's K steps are complete ...
-    elapsed = time.perf_counter() - t0           # ... so its clock stops here; the closing barrier below is not part of the workload
-    barrier()
-    gpu_ms = ev0.elapsed_time(ev1)
-    if distributed:
-        elapsed = reduce_max(elapsed, dist, red_dev)  # job time = slowest rank (all ranks started together behind the opening barrier)
+    def run_mode(scaling, steps, warmup, clock_warm_ms):
+        """One complete measurement in one scaling mode; returns a dict of this job's numbers (rank 0's view after the MAX-reduce)."""
+        x = rank_inputs(n, B, world, rank, scaling)   # strong: this rank's contiguous slice of the ONE global batch
+        N = x.shape[0]
+        d_in = torch.from_numpy(np.ascontiguousarray(x)).to(dev)
+        d_out = torch.empty((max(N, 1), 2 * n * n), dtype=torch.float32, device=dev)
+        step = lib.prepare_forward_dynamics_gradient_device(d_in, N, d_out, stream=stream.cuda_stream)  # ctypes arguments built once
+        warm_launches = 0
+        if clock_warm_ms > 0:  # disclosed, untimed: keep the GPU busy so that the clocks have ramped up before anything is timed
+            t_end = time.perf_counter() + clock_warm_ms * 1e-3
+            while time.perf_counter() < t_end:
+                for _ in range(64):
+                    step()
+                warm_launches += 64
+                torch.cuda.synchronize(dev)
+        for _ in range(warmup):
+            step()
+        barrier()
+        # ---- timed region: exactly K steps; ONE HIP event pair on the launch stream brackets it
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        ev0.record(stream)
+        for _ in range(steps):
+            step()
+        ev1.record(stream)
+        torch.cuda.synchronize(dev)                 # this rank's K steps are complete ...
+        elapsed = time.perf_counter() - t0           # ... so its clock stops here; the closing barrier below is not part of the workload
+        barrier()
+        gpu_ms = ev0.elapsed_time(ev1)
+        if distributed:
+            elapsed = reduce_max(elapsed, dist, red_dev)  # job time = slowest rank (all ranks started together behind the opening barrier)
+        # ---- diagnostic pass (not part of `value`): one event per launch -> per-launch distribution
+        evs = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+        evs[0].record(stream)
+        for i in range(steps):
+            step()
+            evs[i + 1].record(stream)
+        torch.cuda.synchronize(dev)
+        per = np.array([evs[i].elapsed_time(evs[i + 1]) for i in range(steps)]) * 1e3  # us
+        barrier()
+        total = (B if scaling == "strong" else world * B) * steps
+        return {"x": x, "d_out": d_out, "N": N, "elapsed": elapsed, "gpu_ms": gpu_ms, "per_launch_us": per, "solves": total,
+                "warm_launches": warm_launches}
+
+    scaling = args.scaling
+    r = run_mode(scaling, args.steps, args.warmup, args.clock_warm_ms)
+    if args.dump:
+        os.makedirs(args.dump, exist_ok=True)
+        np.save(os.path.join(args.dump, "out_rank%d.npy" % rank), r["d_out"][:r["N"]].cpu().numpy())
+    other = None
+    if world > 1 and not args.no_extras:  # the other scaling mode as a second key (same protocol, clocks already warm)
+        other_mode = "weak" if scaling == "strong" else "strong"
+        o = run_mode(other_mode, args.steps, args.warmup, 0.0)
+        other = {"scaling": other_mode, "value": o["solves"] / o["elapsed"], "unit": "solves/s", "ms_per_step": 1e3 * o["elapsed"] / args.steps,
+                 "batch_per_gpu": o["N"], "global_batch": B if other_mode == "strong" else world * B}
 
     if rank == 0:
-        solves = world * N * args.steps
-        bytes_per_solve = 4 * (3 * n + 2 * n * n)  # 476 B for n = 7
-        launch_ms = gpu_ms / args.steps             # average launch duration on the launch stream (HIP events), incl. launch boundaries
+        N = r["N"]
+        bytes_per_solve = 4 * (3 * n + 2 * n * n)   # SURVEY.md 8(d): 476 B for n = 7
+        launch_ms = r["gpu_ms"] / args.steps          # average launch duration on the launch stream (HIP events), incl. launch boundaries
         achieved = bytes_per_solve * N / (launch_ms * 1e-3) / 1e9
-        traffic = None
-        pmc_file = os.path.join(REPO, "profiles", "pmc_traffic.json")
-        if os.path.exists(pmc_file):
-            try:
-                traffic = json.load(open(pmc_file)).get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
+        per = r["per_launch_us"]
+        pmc, traffic, valu_insts = None, None, None
+        try:
+            pmc = json.load(open(os.path.join(REPO, PMC_FILE)))
+            if N == pmc.get("batch"):
+                traffic, valu_insts = pmc.get("hbm_bytes_per_launch"), pmc.get("sq_insts_valu_per_launch")
+        except Exception:
+            pmc = None
         line = {
             "metric": "forward_dynamics_gradient solves/sec, iiwa-14 batch=16384",
-            "value": solves / elapsed,
+            "value": r["solves"] / r["elapsed"],
             "unit": "solves/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
-            "ms_per_step": 1e3 * elapsed / args.steps,
+            "ms_per_step": 1e3 * r["elapsed"] / args.steps,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": scaling,
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": "iiwa14 (7-DoF chain) forward_dynamics_gradient, batch=%d per GPU, device-resident q_qd_u -> df_du" % N,
-                       "robot": ROBOT, "batch_per_gpu": N, "global_batch": world * N, "sharding": "batch axis, no collective"},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+            "config": {"workload": "iiwa14 (7-DoF chain) forward_dynamics_gradient, global batch %d, device-resident q_qd_u -> df_du" % (B if scaling == "strong" else world * B),
+                       "robot": ROBOT, "batch_per_gpu": N, "global_batch": B if scaling == "strong" else world * B,
+                       "sharding": "contiguous ranges of the batch axis (ceil(B/G) solves per GPU), no collective" if scaling == "strong" else "one batch per GPU, no collective"},
+            "clock_warm_ms": args.clock_warm_ms, "clock_warm_launches": r["warm_launches"],
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": traffic, "traffic_source": (PMC_FILE + " (rocprofv3 --pmc passes of this kernel build, not measured in this run)") if traffic else None,
                          "kernel": "forward_dynamics_gradient_kernel<float>", "launch_us": 1e3 * launch_ms,
+                         "launch_us_median": float(np.median(per)), "launch_us_min": float(per.min()), "launch_us_max": float(per.max()),
+                         "launch_us_note": "launch_us = event pair around the K timed launches / K; median/min/max = diagnostic pass with one event per launch (event markers add ~1 us between launches)",
                          "algorithmic_bytes_per_launch": bytes_per_solve * N,
-                         "note": "the path is fp32-VALU bound (AI ~110 flop/B): see valu_frac"},
-            "valu_frac": (N / (launch_ms * 1e-3)) * FLOPS_PER_SOLVE / (FP32_PEAK_TFLOPS * 1e12),
+                         "note": "the path is fp32-VALU bound (AI ~110 flop/B): see valu_issue_frac"},
+            # solves/s x the REFERENCE's 53 kflop per solve / peak fp32: a reference-equivalent rate, NOT the utilisation of this kernel
+            "ref_equiv_valu_frac": (N / (launch_ms * 1e-3)) * FLOPS_PER_SOLVE_REFERENCE / (FP32_PEAK_TFLOPS * 1e12),
+            # VALU issue utilisation: wave-instructions (SQ_INSTS_VALU, committed PMC pass) x 2 issue cycles / (SIMDs x kernel cycles at 2.4 GHz)
+            "valu_issue_frac": (valu_insts * 2.0 / (N_SIMDS * launch_ms * 1e-3 * CLOCK_GHZ * 1e9)) if valu_insts else None,
+            "valu_issue_frac_source": (PMC_FILE + ": sq_insts_valu_per_launch x 2 cycles / (1024 SIMDs x launch_us x 2.4 GHz)") if valu_insts else None,
         }
+        if other is not None:
+            line["other_scaling"] = other
+        if world == 1 and not args.no_extras:
+            line["copy_bw_measured_GBps"] = measured_copy_bandwidth(torch, dev)
+            line["roofline"]["frac_of_measured_copy_bw"] = achieved / line["copy_bw_measured_GBps"]
+            # end-to-end incl. H2D/D2H through the host-buffer C-ABI entry point (pageable NumPy memory); never `value`
+            xh = r["x"]
+            lib.forward_dynamics_gradient_host(xh)
+            t0 = time.perf_counter()
+            reps = 20
+            for _ in range(reps):
+                lib.forward_dynamics_gradient_host(xh)
+            line["end_to_end_solves_per_s"] = reps * xh.shape[0] / (time.perf_counter() - t0)
+            line["end_to_end_note"] = "grid_forward_dynamics_gradient_host: H2D + kernel + D2H per call, pageable host memory, PCIe-inclusive"
         if not args.no_cpu_baseline and world == 1:
             # the only place the oracle (test infrastructure) is touched: the CPU baseline leg, which also spot-checks the GPU result
-            line["cpu_baseline"] = cpu_baseline(robot, x)
+            line["cpu_baseline"] = cpu_baseline(robot, r["x"])
             from oracle.rbd_oracle import Oracle
 
-            got = d_out[:32].cpu().numpy()
-            ref, _ = Oracle(robot).fd_grad_batch(x[:32].astype(np.float64))
+            got = r["d_out"][:32].cpu().numpy()
+            ref, _ = Oracle(robot).fd_grad_batch(r["x"][:32].astype(np.float64))
             err = float(max(np.abs(got[k] - ref[k]).max() / np.abs(ref[k]).max() for k in range(32)))
             assert args.no_parity or err <= 1e-4, "parity check failed: %g" % err
             line["cpu_baseline"]["gpu_parity_max_rel_err_vs_fp64_oracle"] = err

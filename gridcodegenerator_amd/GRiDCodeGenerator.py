@@ -14,6 +14,51 @@ import numpy as np
 
 from .robot import DuckRobot
 
+# Generation-time tuning knobs.  They are reachable ONLY through the constructor (``GRiDCodeGenerator(robot, tuning={...})``): nothing in
+# the process environment changes the generated code.  The "ablation" group emits kernels whose RESULTS ARE WRONG on purpose (timing
+# experiments of tools/); it must be requested with the extra key ``"allow_wrong_results": True``.
+TUNING_DEFAULTS = {
+    "cols_per_lane": 2,         # 2: lane j owns d/dq_j and d/dqd_j; 1: one derivative column per lane (lane group = next pow2 >= 2n)
+    "gradient_walk": "auto",    # auto | registers | lds | tipframe | branch: which formulation forward_dynamics_gradient is emitted in
+    "fuse_fd": True,            # fused M^-1 || RNEA sweep of the column-walk forward dynamics (robots with <= 9 joints)
+    "reuse_rnea": False,        # column walk re-uses v, I v, fx(v) I v of the RNEA(qdd=0) pass (measured slower: 16.6 vs 15.0 us)
+    "min_waves": 0,             # second __launch_bounds__ argument (minimum waves per SIMD); 0 = compiler's choice
+    "so_unroll": None,          # inner-loop unrolling of idsva_so (None = full)
+    "dpp_asm": True,            # lane-group scans as single v_fmac_f32_dpp instructions (inline asm) instead of builtin DPP move + FMA
+    "tip_chain": "select",      # select | lds: how the tip-frame chain hands (R, p) to the owning lane
+    "nt_store": True,           # non-temporal output stores
+}
+TUNING_ABLATION = {
+    "debug_stop": 0,            # truncate the kernel after a phase / cycle stamps (tools/prof_ablation.sh, tools/phase_stamps.py)
+    "no_pins": False,           # drop the register pins
+    "no_wave_barrier": False,   # drop the wave barrier of grid_wave_sync (fences only)
+    "round_probe": (),          # accuracy diagnosis (tools/precision_probe.py): stages of the tip-frame inner whose results are rounded to fp32
+                                # inside the T = double instantiation - shows which stage's fp32 rounding the final error comes from
+}
+
+
+def resolve_tuning(tuning=None, COLS_PER_LANE=None):
+    t = dict(TUNING_DEFAULTS)
+    t.update(TUNING_ABLATION)
+    tuning = dict(tuning or {})
+    allow = bool(tuning.pop("allow_wrong_results", False))
+    for k, v in tuning.items():
+        if k in TUNING_ABLATION:
+            if v != TUNING_ABLATION[k] and not allow:
+                raise ValueError("tuning key %r produces wrong results by design; pass allow_wrong_results=True with it (timing experiments only)" % k)
+        elif k not in TUNING_DEFAULTS:
+            raise ValueError("unknown tuning key %r (known: %s)" % (k, ", ".join(sorted(TUNING_DEFAULTS))))
+        t[k] = v
+    if COLS_PER_LANE is not None:
+        t["cols_per_lane"] = int(COLS_PER_LANE)
+    if t["gradient_walk"] not in ("auto", "registers", "lds", "tipframe", "branch"):
+        raise ValueError("tuning['gradient_walk'] must be auto, registers, lds, tipframe or branch")
+    if t["cols_per_lane"] not in (1, 2):
+        raise ValueError("tuning['cols_per_lane'] must be 1 or 2")
+    if t["tip_chain"] not in ("select", "lds"):
+        raise ValueError("tuning['tip_chain'] must be select or lds")
+    return t
+
 
 class GRiDCodeGenerator:
     # emission primitives, device math, model constants (free functions taking self, like the reference's layout)
@@ -52,7 +97,13 @@ class GRiDCodeGenerator:
     # NumPy debug helpers with the reference's names and signatures (reference GRiDCodeGenerator.py:50-51, README "Additional Features")
     from ._test import test_rnea, test_minv, test_rnea_grad, test_fd_grad
 
-    def __init__(self, robotObj, DEBUG_MODE=False, NEED_PRINT_MAT=False, USE_DYNAMIC_SHARED_MEM=True, FILE_NAMESPACE="grid", COLS_PER_LANE=None):
+    def __init__(self, robotObj, DEBUG_MODE=False, NEED_PRINT_MAT=False, USE_DYNAMIC_SHARED_MEM=True, FILE_NAMESPACE="grid", COLS_PER_LANE=None, tuning=None):
+        if not USE_DYNAMIC_SHARED_MEM:
+            # reference GRiDCodeGenerator.py:54,61 / helpers/_topology_helpers.py:151-153: static `__shared__ T s_XImats[...]` per function.
+            # The lane-group kernels size their LDS by the caller's block size (solves per block), which a static array cannot express.
+            raise NotImplementedError("USE_DYNAMIC_SHARED_MEM=False (static __shared__ arrays) is not supported by the lane-group kernels: "
+                                      "their LDS slice count depends on the launch's block size; keep the default (dynamic LDS)")
+        self.tuning = resolve_tuning(tuning, COLS_PER_LANE)
         self.robot = robotObj
         self.model = DuckRobot(robotObj)  # numeric tables; raises for robots outside the supported joint models
         self.code_str = ""
@@ -67,8 +118,7 @@ class GRiDCodeGenerator:
             raise NotImplementedError("robots with more than 64 joints need more than one wavefront per solve")
         # COLS_PER_LANE (tuning knob, not in the reference API): 2 -> lane j owns d/dq_j and d/dqd_j (lane group = next pow2 >= n);
         # 1 -> first half of the group owns the d/dq columns, second half the d/dqd columns (lane group = next pow2 >= 2n)
-        if COLS_PER_LANE is None:
-            COLS_PER_LANE = int(__import__("os").environ.get("GRID_COLS_PER_LANE", "2"))
+        COLS_PER_LANE = self.tuning["cols_per_lane"]
         if COLS_PER_LANE == 1 and 2 * n > 64:
             COLS_PER_LANE = 2
         self.cols_per_lane = COLS_PER_LANE
@@ -79,12 +129,9 @@ class GRiDCodeGenerator:
         self.lanes_per_solve = lanes          # lane j of a group <-> joint j; 6 lanes also carry the articulated inertia columns
         # derivative-walk form (see algorithms/_inverse_dynamics_gradient.py): VGPR-resident backward sweep for shallow trees, LDS-assisted
         # forward accumulation for deep ones; and whether the gradient walk of forward_dynamics_gradient re-uses v, I v, fx(v) I v of the RNEA(qdd=0) pass
-        import os as _os
         depth_max = max(self.model.depth) + 1
         nslots = len(self.gen_gradient_slots())
-        mode = _os.environ.get("GRID_GRADIENT_WALK", "auto")
-        if mode not in ("auto", "registers", "lds", "tipframe", "branch"):
-            raise ValueError("GRID_GRADIENT_WALK must be auto, registers, lds, tipframe or branch")
+        mode = self.tuning["gradient_walk"]
         self.register_walk = (mode == "registers") or (mode in ("auto", "tipframe") and depth_max * 6 * (1 + nslots) <= 200)
         # forward_dynamics_gradient of serial revolute chains is assembled in the tip link's frame (algorithms/_tip_frame_gradient.py);
         # every other robot, and every other kernel, uses the column walk selected above
@@ -96,7 +143,7 @@ class GRiDCodeGenerator:
         tip_ok = bool(chains and equal and all(s_ < 3 for s_ in m_.S_index) and COLS_PER_LANE == 2 and lanes <= 16)
         self.tip_L, self.tip_nseg = (segs[0][1], len(segs)) if tip_ok else (n, 1)
         if mode == "tipframe" and not tip_ok:
-            raise NotImplementedError("GRID_GRADIENT_WALK=tipframe needs a serial chain of revolute joints (or a forest of equal such chains) with at most 16 joints")
+            raise NotImplementedError("gradient_walk=tipframe needs a serial chain of revolute joints (or a forest of equal such chains) with at most 16 joints")
         self.tip_frame = tip_ok and mode in ("auto", "tipframe") and not DEBUG_MODE  # (DEBUG_MODE prints M^-1, which this path never forms)
         # branched robots with revolute joints: forward_dynamics_gradient with every branch in the frame of its own tip link
         # (algorithms/_branch_frame_gradient.py); the other kernels of such robots stay on the column walk
@@ -109,7 +156,7 @@ class GRiDCodeGenerator:
             # (20-joint chain, 4 096 solves: 99 us against 90 us on the column walk; 27-joint random tree with 651: 141 against 154 us)
             self.branch_plan = None
         if mode == "branch" and self.branch_plan is None:
-            raise NotImplementedError("GRID_GRADIENT_WALK=branch needs revolute joints and branches that fit the 16-lane rows of the lane group")
+            raise NotImplementedError("gradient_walk=branch needs revolute joints and branches that fit the 16-lane rows of the lane group")
         self.branch_frame = self.branch_plan is not None
         if mode == "branch":
             self.tip_frame = False
@@ -117,9 +164,9 @@ class GRiDCodeGenerator:
             self.tip_L = self.branch_plan["maxLb"]  # (length of the DPP scans)
         self.branch_tab_offset = 54 * n + (len(self.gen_tip_frame_link_constants()) if self.tip_frame else 0)
         self.branch_components = self.branch_frame and not self.tip_frame  # the stand-alone kernels of branched robots run the same path
-        self.reuse_rnea = self.register_walk and n <= 9 and _os.environ.get("GRID_FUSE_FD", "1") == "1" and _os.environ.get("GRID_REUSE_RNEA", "0") == "1"  # measured: 16.6 us vs 15.0 us per launch with re-use (extra LDS traffic on the critical path), so off by default
+        self.reuse_rnea = self.register_walk and n <= 9 and self.tuning["fuse_fd"] and self.tuning["reuse_rnea"]  # measured: 16.6 us vs 15.0 us per launch with re-use (extra LDS traffic on the critical path), so off by default
         # tuning knob: minimum waves per SIMD the register allocator must leave room for (second __launch_bounds__ argument); 0 = compiler's choice
-        self.min_waves_per_eu = int(__import__("os").environ.get("GRID_MIN_WAVES", "0"))
+        self.min_waves_per_eu = int(self.tuning["min_waves"])
         self.minv_ld = (n + 3) // 4 * 4  # leading dimension of the dense M^-1 in LDS
         self.suggested_threads = 256
         self.max_threads = 512                # __launch_bounds__: keeps 256 VGPRs available per lane
@@ -135,12 +182,17 @@ class GRiDCodeGenerator:
         self.gen_add_code_line("#define XIMAT_SIZE 36")
 
     def gen_add_gpu_err(self):
-        self.gen_add_func_doc("Check for runtime errors using the HIP API", [], [], None)
+        self.gen_add_func_doc("Check for runtime errors using the HIP API",
+                              ["default: print and exit like the reference's gpuAssert; a host program (or the C-ABI shim, which must not take its",
+                               "caller's process down) may define GRID_ON_GPU_ERROR(code, file, line) before including this header to do something else"], [], None)
+        self.gen_add_code_line("#ifndef GRID_ON_GPU_ERROR")
+        self.gen_add_code_line("#define GRID_ON_GPU_ERROR(code, file, line) { fprintf(stderr,\"GPUassert: %s %s %d\\n\", hipGetErrorString(code), file, line); hipDeviceReset(); exit(code); }")
+        self.gen_add_code_line("#endif")
         self.gen_add_code_line("__host__")
         self.gen_add_code_line("inline void gpuAssert(hipError_t code, const char *file, const int line, bool abort=true){", True)
         self.gen_add_code_line("if (code != hipSuccess){", True)
-        self.gen_add_code_line("fprintf(stderr,\"GPUassert: %s %s %d\\n\", hipGetErrorString(code), file, line);")
-        self.gen_add_code_line("if (abort){hipDeviceReset(); exit(code);}")
+        self.gen_add_code_line("if (abort) { GRID_ON_GPU_ERROR(code, file, line); }")
+        self.gen_add_code_line("else { fprintf(stderr,\"GPUassert: %s %s %d\\n\", hipGetErrorString(code), file, line); }")
         self.gen_add_end_control_flow()
         self.gen_add_end_control_flow()
         self.gen_add_code_line("#define gpuErrchk(err) {gpuAssert(err, __FILE__, __LINE__);}")
@@ -201,18 +253,21 @@ class GRiDCodeGenerator:
                                      "const int IDSVA_SO_LDS_PER_SOLVE = %d; // compact slice of the idsva_so kernels: q | qd | qdd | scratch" % sl_,
                                      "const int IDSVA_SO_SCRATCH_PER_SOLVE = %d; // X(q) / per-joint records + a zero qdd vector" % scr_,
                                      "const int IDSVA_SO_STAGE_PER_SOLVE = %d;" % stg_,
-                                     "const int IDSVA_SO_DYNAMIC_SHARED_MEM_COUNT = (IDSVA_SO_SUGGESTED_THREADS/GRID_LANES_PER_SOLVE)*(IDSVA_SO_LDS_PER_SOLVE + IDSVA_SO_STAGE_PER_SOLVE);"])
+                                     "const int IDSVA_SO_MAX_SOLVES_PER_BLOCK = IDSVA_SO_SUGGESTED_THREADS/GRID_LANES_PER_SOLVE; // lane groups of larger blocks retire",
+                                     "const int IDSVA_SO_DYNAMIC_SHARED_MEM_COUNT = IDSVA_SO_MAX_SOLVES_PER_BLOCK*(IDSVA_SO_LDS_PER_SOLVE + IDSVA_SO_STAGE_PER_SOLVE);"])
             st_ = self.gen_fdsva_so_stage_size()
             self.gen_add_code_lines(["const int FDSVA_SO_SUGGESTED_THREADS = 64; // fdsva_so keeps the 4 n^3 idsva_so tensors of every solve in LDS: fewer solves per block",
                                      "const int FDSVA_SO_STAGE_PER_SOLVE = " + str(st_) + "; // df/du (2 n^2, padded) + idsva_so (4 n^3), behind the block's slices",
-                                     "const int FDSVA_SO_DYNAMIC_SHARED_MEM_COUNT = (FDSVA_SO_SUGGESTED_THREADS/GRID_LANES_PER_SOLVE)*(GRID_LDS_PER_SOLVE + FDSVA_SO_STAGE_PER_SOLVE);"])
+                                     "const int FDSVA_SO_MAX_SOLVES_PER_BLOCK = FDSVA_SO_SUGGESTED_THREADS/GRID_LANES_PER_SOLVE;",
+                                     "const int FDSVA_SO_DYNAMIC_SHARED_MEM_COUNT = FDSVA_SO_MAX_SOLVES_PER_BLOCK*(GRID_LDS_PER_SOLVE + FDSVA_SO_STAGE_PER_SOLVE);"])
         self.gen_add_code_lines(["// dynamic LDS (bytes) a launch with `threads` threads per block needs: one slice + one staging record per lane group of the block.",
                                  "// The host wrappers size their launches with it (the *_DYNAMIC_SHARED_MEM_COUNT constants are this amount for SUGGESTED_THREADS in",
                                  "// elements of T; a block may not exceed the CU's 160 KB: large robots in double precision need fewer threads per block)",
                                  "template <typename T>",
-                                 "__host__ inline size_t grid_lds_bytes(const dim3 threads, const int lds_per_solve = GRID_LDS_PER_SOLVE, const int out_per_solve = GRID_OUT_PER_SOLVE) {",
+                                 "__host__ inline size_t grid_lds_bytes(const dim3 threads, const int lds_per_solve = GRID_LDS_PER_SOLVE, const int out_per_solve = GRID_OUT_PER_SOLVE,",
+                                 "                                      const int max_groups = GRID_MAX_SOLVES_PER_BLOCK) {",
                                  "    int gpb = static_cast<int>(threads.x*threads.y)/GRID_LANES_PER_SOLVE;",
-                                 "    if (gpb > GRID_MAX_SOLVES_PER_BLOCK) {gpb = GRID_MAX_SOLVES_PER_BLOCK;}",
+                                 "    if (gpb > max_groups) {gpb = max_groups;} // (the kernels retire lane groups beyond their cap)",
                                  "    if (gpb < 1) {gpb = 1;}",
                                  "    return static_cast<size_t>(gpb)*(lds_per_solve + out_per_solve)*sizeof(T);",
                                  "}"])
@@ -239,9 +294,9 @@ class GRiDCodeGenerator:
             unused = [u for u in unused if u not in ("d_idsva_so", "h_idsva_so", "d_df2", "h_df2")]
         code = ["gridData<T> *hd_data = (gridData<T> *)malloc(sizeof(gridData<T>));",
                 "// device buffers of the dynamics algorithms"]
-        code += ["gpuErrchk(hipMalloc((void**)&hd_data->" + nm + ", " + sz + "*NUM_TIMESTEPS*sizeof(T)));" for nm, sz in dev]
+        code += ["gpuErrchk(hipMalloc((void**)&hd_data->" + nm + ", static_cast<size_t>(NUM_TIMESTEPS)*" + sz + "*sizeof(T)));" for nm, sz in dev]
         code += ["// pinned host buffers (so the host wrappers' hipMemcpyAsync really is asynchronous)"]
-        code += ["gpuErrchk(hipHostMalloc((void**)&hd_data->" + nm + ", " + sz + "*NUM_TIMESTEPS*sizeof(T), hipHostMallocDefault));" for nm, sz in host]
+        code += ["gpuErrchk(hipHostMalloc((void**)&hd_data->" + nm + ", static_cast<size_t>(NUM_TIMESTEPS)*" + sz + "*sizeof(T), hipHostMallocDefault));" for nm, sz in host]
         code += ["// buffers of algorithms that this generator does not emit (kinematics, CRBA, second order) stay null"]
         code += ["hd_data->" + nm + " = nullptr;" for nm in unused]
         code += ["return hd_data;"]

@@ -324,8 +324,7 @@ def _emit_branch_inner(self, mode, use_thread_group=False):
     A("template <typename T>")
     A("__device__ __forceinline__")
     A("void %s(%s) {" % (fname, fsig), True)
-    import os
-    ts_mode = mode == "fdgrad" and os.environ.get("GRID_DEBUG_STOP", "0") == "20"  # profiling build: per-wave cycle stamps at the phase boundaries replace the first outputs
+    ts_mode = mode == "fdgrad" and self.tuning["debug_stop"] == 20  # profiling build: per-wave cycle stamps at the phase boundaries replace the first outputs
 
     def TS(i):
         if ts_mode:

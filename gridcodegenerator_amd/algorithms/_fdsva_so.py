@@ -124,7 +124,7 @@ def gen_fdsva_so_kernel(self, use_thread_group=False, single_call_timing=False):
     self.gen_add_code_line("template <typename T>")
     self.gen_add_code_line("__global__ GRID_LAUNCH_BOUNDS")
     self.gen_add_code_line(func_def, True)
-    self.gen_kernel_prologue("GRID_LDS_PER_SOLVE")
+    self.gen_kernel_prologue("GRID_LDS_PER_SOLVE", "FDSVA_SO_MAX_SOLVES_PER_BLOCK")
     self.gen_add_code_lines(["T *s_q_qd_u = &s_mem[GRID_OFF_IN]; T *s_q = s_q_qd_u; T *s_qd = &s_q_qd_u[%d]; T *s_u = &s_q_qd_u[%d];" % (n, 2 * n),
                              "T *s_df_du = &s_out_all[grp*%d]; T *s_idsva_so = s_df_du + %d;" % (stage, stage - 4 * n3)])
     if single_call_timing:
@@ -169,7 +169,7 @@ def gen_fdsva_so_host(self, mode=0):
     self.gen_add_code_line("// then call the kernel")
     if single_call_timing:
         self.gen_add_code_line("struct timespec start, end; clock_gettime(CLOCK_MONOTONIC,&start);")
-    self.gen_add_code_lines(["hipLaunchKernelGGL((" + kern + "),block_dimms,thread_dimms,FDSVA_SO_DYNAMIC_SHARED_MEM_COUNT*sizeof(T),0,hd_data->d_df2,hd_data->d_q_qd_u,stride_q_qd_u,d_robotModel,gravity,num_timesteps);",
+    self.gen_add_code_lines(["hipLaunchKernelGGL((" + kern + "),block_dimms,thread_dimms,grid_lds_bytes<T>(thread_dimms, GRID_LDS_PER_SOLVE, FDSVA_SO_STAGE_PER_SOLVE, FDSVA_SO_MAX_SOLVES_PER_BLOCK),0,hd_data->d_df2,hd_data->d_q_qd_u,stride_q_qd_u,d_robotModel,gravity,num_timesteps);",
                              "gpuErrchk(hipGetLastError()); gpuErrchk(hipDeviceSynchronize());"])
     if single_call_timing:
         self.gen_add_code_line("clock_gettime(CLOCK_MONOTONIC,&end);")

@@ -54,8 +54,7 @@ def gen_forward_dynamics_inner(self, use_thread_group=False):
     self.gen_add_code_line("__device__ __forceinline__")
     self.gen_add_code_line("void forward_dynamics_inner(T *s_qdd, const T *s_qd, const T *s_u, const T *s_X, T *s_U, T *s_T, T *s_Minv, const robotModel<T> *d_robotModel, const T gravity, const int lane) {", True)
     self.gen_add_code_line("T c[%d];" % n)
-    import os
-    if os.environ.get("GRID_FUSE_FD", "1") == "0" or n > 9:  # the fused form keeps every link's RNEA vectors live (18 VGPRs per joint): small robots only
+    if (not self.tuning["fuse_fd"]) or n > 9:  # the fused form keeps every link's RNEA vectors live (18 VGPRs per joint): small robots only
         self.gen_direct_minv_inner_function_call(use_thread_group)
         self.gen_inverse_dynamics_inner_function_call(use_thread_group, True, False)
         self.gen_forward_dynamics_finish_function_call(use_thread_group)

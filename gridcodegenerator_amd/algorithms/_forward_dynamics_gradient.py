@@ -28,8 +28,7 @@ def gen_forward_dynamics_gradient_kernel_max_temp_mem_size(self):
 def gen_forward_dynamics_gradient_inner_python(self, use_thread_group=False, use_qdd_Minv_input=False, s_df_du_name="s_df_du"):
     """Emits the body shared by the device functions and the kernels; expects s_q/s_qd/(s_u)/s_qdd/s_Minv/s_X/s_U/s_T to be bound."""
     n = self.model.n
-    import os
-    stop = int(os.environ.get("GRID_DEBUG_STOP", "0"))  # timing ablation only (results are wrong when set): 1 = X update, 2 = +Minv, 3 = +RNEA/qdd, 4 = +gradient walk
+    stop = int(self.tuning["debug_stop"])  # timing ablation only (results are wrong when set): 1 = X update, 2 = +Minv, 3 = +RNEA/qdd, 4 = +gradient walk
     if getattr(self, "branch_frame", False) and stop in (0, 20) and not use_qdd_Minv_input:  # trees of revolute joints: one fused inner, every branch in its tip link's frame
         self.gen_forward_dynamics_gradient_inner_branch_function_call(use_thread_group, s_df_du_name)
         return
@@ -137,8 +136,7 @@ def gen_forward_dynamics_gradient_kernel(self, use_thread_group=False, use_qdd_M
     self.gen_add_code_line("__global__ GRID_LAUNCH_BOUNDS")
     self.gen_add_code_line(func_def, True)
     self.gen_kernel_prologue("GRID_LDS_PER_SOLVE" if use_qdd_Minv_input else "FD_DU_LDS_PER_SOLVE")
-    import os
-    if os.environ.get("GRID_DEBUG_STOP", "0") == "9":  # timing ablation only: an empty kernel (launch + dispatch cost)
+    if self.tuning["debug_stop"] == 9:  # timing ablation only: an empty kernel (launch + dispatch cost)
         self.gen_add_code_line("if (NUM_TIMESTEPS > -1) {return;}")
     if use_qdd_Minv_input:
         self.gen_add_code_line("T *s_q_qd = &s_mem[GRID_OFF_IN]; T *s_q = s_q_qd; T *s_qd = &s_q_qd[%d]; T *s_qdd = &s_mem[GRID_OFF_QDD];" % n)

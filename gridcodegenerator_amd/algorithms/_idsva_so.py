@@ -202,10 +202,9 @@ for (int m = 0; m < @N@; m++) {
     }
 }
 """.replace("@N@", str(n)).replace("@N3@", str(n3))
-    import os
     # timing ablation only (GRID_DEBUG_STOP=30): everything is computed, (almost) nothing is stored
-    lines = lines.replace("@UNROLL_L@", os.environ.get("GRID_SO_UNROLL", str(n)))  # tuning knob: inner-loop unrolling of idsva_so (full: -7 % vs none on the 7-DoF arm)
-    lines = lines.replace("@NOSTORE@", " && (gravity < static_cast<T>(-1e30))" if os.environ.get("GRID_DEBUG_STOP", "0") == "30" else "")
+    lines = lines.replace("@UNROLL_L@", str(self.tuning["so_unroll"] or n))  # tuning knob: inner-loop unrolling of idsva_so (full: -7 % vs none on the 7-DoF arm)
+    lines = lines.replace("@NOSTORE@", " && (gravity < static_cast<T>(-1e30))" if self.tuning["debug_stop"] == 30 else "")
     for line in lines.strip("\n").split("\n"):
         self.gen_add_code_line(line)
     self.gen_add_end_function()
@@ -256,7 +255,7 @@ def gen_idsva_so_kernel(self, use_thread_group=False, use_qdd_input=False, singl
     self.gen_add_code_line(func_def, True)
     sl, scratch, stage, threads = self.gen_idsva_so_lds_layout()
     pad3n = (3 * n + 3) // 4 * 4
-    self.gen_kernel_prologue("IDSVA_SO_LDS_PER_SOLVE")
+    self.gen_kernel_prologue("IDSVA_SO_LDS_PER_SOLVE", "IDSVA_SO_MAX_SOLVES_PER_BLOCK")
     self.gen_add_code_line("T *s_q_qd_u = s_mem; T *s_q = s_q_qd_u; T *s_qd = &s_q_qd_u[%d]; T *s_qdd = &s_q_qd_u[%d]; T *s_scratch = &s_mem[%d]; (void)s_qdd;" % (n, 2 * n, pad3n))
     self.gen_add_code_line("T *s_idsva_so = &s_out_all[grp*%d]; // this solve's output record, staged in LDS" % stage)
     if single_call_timing:
@@ -309,8 +308,8 @@ def gen_idsva_so_host(self, mode=0):
     self.gen_add_code_line("// then call the kernel")
     if single_call_timing:
         self.gen_add_code_line("struct timespec start, end; clock_gettime(CLOCK_MONOTONIC,&start);")
-    self.gen_add_code_lines(["if (USE_QDD_FLAG) {hipLaunchKernelGGL((" + kern + "),block_dimms,thread_dimms,IDSVA_SO_DYNAMIC_SHARED_MEM_COUNT*sizeof(T),0,hd_data->d_idsva_so,hd_data->d_q_qd_u,stride_q_qd,hd_data->d_qdd,d_robotModel,gravity,num_timesteps);}",
-                             "else {hipLaunchKernelGGL((" + kern + "),block_dimms,thread_dimms,IDSVA_SO_DYNAMIC_SHARED_MEM_COUNT*sizeof(T),0,hd_data->d_idsva_so,hd_data->d_q_qd_u,stride_q_qd,d_robotModel,gravity,num_timesteps);}",
+    self.gen_add_code_lines(["if (USE_QDD_FLAG) {hipLaunchKernelGGL((" + kern + "),block_dimms,thread_dimms,grid_lds_bytes<T>(thread_dimms, IDSVA_SO_LDS_PER_SOLVE, IDSVA_SO_STAGE_PER_SOLVE, IDSVA_SO_MAX_SOLVES_PER_BLOCK),0,hd_data->d_idsva_so,hd_data->d_q_qd_u,stride_q_qd,hd_data->d_qdd,d_robotModel,gravity,num_timesteps);}",
+                             "else {hipLaunchKernelGGL((" + kern + "),block_dimms,thread_dimms,grid_lds_bytes<T>(thread_dimms, IDSVA_SO_LDS_PER_SOLVE, IDSVA_SO_STAGE_PER_SOLVE, IDSVA_SO_MAX_SOLVES_PER_BLOCK),0,hd_data->d_idsva_so,hd_data->d_q_qd_u,stride_q_qd,d_robotModel,gravity,num_timesteps);}",
                              "gpuErrchk(hipGetLastError()); gpuErrchk(hipDeviceSynchronize());"])
     if single_call_timing:
         self.gen_add_code_line("clock_gettime(CLOCK_MONOTONIC,&end);")

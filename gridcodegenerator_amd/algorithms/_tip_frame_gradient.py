@@ -178,8 +178,7 @@ def gen_tip_frame_library(self):
             self.gen_add_code_line("#pragma unroll")
             self.gen_add_code_line("for (int r = 0; r < N; r++) { x[r] += mk[%d]*%s<%d>(x[r]); }" % (s_, fn, k))
         self.gen_add_end_function()
-    import os
-    if os.environ.get("GRID_DPP_ASM", "1") == "1":
+    if self.tuning["dpp_asm"]:
         # fp32 device code: one v_fmac_f32_dpp per value and step instead of the v_mov_b32_dpp + v_fma pair the compiler emits for the
         # builtin (it does not fold the DPP move into the FMA).  The hazard recognizer does not look inside inline asm, so every block
         # opens with the 2 wait states a DPP read needs after a VALU write of the same register.
@@ -198,6 +197,16 @@ def gen_tip_frame_library(self):
                 self.gen_add_end_function()
         self.gen_add_code_line("#endif")
     self.gen_add_code_line("")
+
+
+def _probe(self, stage, *arrays):
+    """Accuracy diagnosis only (tuning round_probe): round the named register arrays ("name:len") to fp32 at the end of a stage."""
+    if stage not in tuple(self.tuning.get("round_probe", ())):
+        return
+    for a in arrays:
+        nm, ln = a.split(":")
+        self.gen_add_code_line("#pragma unroll")
+        self.gen_add_code_line("for (int r = 0; r < %s; r++) { %s[r] = static_cast<T>(static_cast<float>(%s[r])); } // round_probe %s" % (ln, nm, nm, stage))
 
 
 def _chain_step(self, i, s_F=None, with_gravity=True):
@@ -419,7 +428,7 @@ def _emit_link_constants_load(self):
         self.gen_add_code_line("const int base = %d*((seg < %d) ? seg : %d), pos = lane - base; // (lanes without a joint follow the last chain with pos >= %d: they match no step)" % (L, nseg, nseg - 1, L))
 
 
-def _emit_ldl_factor(self, A="A", U="Uf", rd="rd"):
+def _emit_ldl_factor(self, A="A", U="Uf", rd="rd", probe=False):
     """In-register U D U^T factorisation of the symmetric n x n matrix A (upper triangle A[i][j], i <= j), eliminating the tip joint
     first: A = Uf diag(1/rd) Uf^T with Uf unit upper triangular.  Wave-uniform (every lane factors the same matrix): n reciprocals,
     n(n-1)/2 multiplies, (n-1)n(n+1)/6 FMAs and no cross-lane traffic.  Diagonal scaling does not affect an unpivoted symmetric
@@ -427,8 +436,9 @@ def _emit_ldl_factor(self, A="A", U="Uf", rd="rd"):
     (Forests: n is the chain length and the matrix is the lane's own diagonal block.)"""
     n = self.tip_L
     for k in range(n - 1, 0, -1):
-        self.gen_add_code_line("const T %s%d = grid_rcp(%s%d_%d);" % (rd, k, A, k, k))
-        self.gen_add_code_line(" ".join("const T %s%d_%d = %s%d_%d*%s%d;" % (U, i, k, A, i, k, rd, k) for i in range(k)))
+        R32 = (lambda e: "static_cast<T>(static_cast<float>(%s))" % e) if probe else (lambda e: e)
+        self.gen_add_code_line("const T %s%d = %s;" % (rd, k, R32("grid_rcp(%s%d_%d)" % (A, k, k))))
+        self.gen_add_code_line(" ".join("const T %s%d_%d = %s;" % (U, i, k, R32("%s%d_%d*%s%d" % (A, i, k, rd, k))) for i in range(k)))
         for j in range(k):
             self.gen_add_code_line(" ".join("%s%d_%d -= %s%d_%d*%s%d_%d;" % (A, i, j, U, i, k, A, j, k) for i in range(j + 1)))
     self.gen_add_code_line("const T %s0 = grid_rcp(%s0_0);" % (rd, A))
@@ -472,8 +482,7 @@ def gen_forward_dynamics_gradient_inner_tip(self, use_thread_group=False, use_qd
     self.gen_add_code_line("template <typename T>")
     self.gen_add_code_line("__device__ __forceinline__")
     self.gen_add_code_line("void %s(%s) {" % (name, sig), True)
-    import os
-    ts_mode = (not use_qdd_Minv_input) and os.environ.get("GRID_DEBUG_STOP", "0") == "20"  # profiling build: per-wave cycle stamps at the phase boundaries replace the first 8 outputs
+    ts_mode = (not use_qdd_Minv_input) and self.tuning["debug_stop"] == 20  # profiling build: per-wave cycle stamps at the phase boundaries replace the first 8 outputs
 
     def TS(i):
         if ts_mode:
@@ -484,7 +493,7 @@ def gen_forward_dynamics_gradient_inner_tip(self, use_thread_group=False, use_qd
     TS(0)
     _emit_link_constants_load(self)
     _emit_chain_decls(self)
-    chain_lds = (not use_qdd_Minv_input) and self.tip_nseg == 1 and os.environ.get("GRID_TIP_CHAIN", "select") == "lds"
+    chain_lds = (not use_qdd_Minv_input) and self.tip_nseg == 1 and self.tuning["tip_chain"] == "lds"
     L = self.tip_L
     for i in range(L - 1, -1, -1):
         _chain_step(self, i, "s_G" if chain_lds else None)
@@ -504,7 +513,7 @@ def gen_forward_dynamics_gradient_inner_tip(self, use_thread_group=False, use_qd
         _emit_assembly(self, s_G="s_X")
         self.gen_add_end_function()
         return
-    stop = int(os.environ.get("GRID_DEBUG_STOP", "0"))  # timing ablation only (results are wrong when set): 5 = chain, 6 = + link setup/bias/record, 7 = + M, factorisation, qdd
+    stop = int(self.tuning["debug_stop"])  # timing ablation only (results are wrong when set): 5 = chain, 6 = + link setup/bias/record, 7 = + M, factorisation, qdd
     ld = self.minv_ld
     if stop == 5:
         self.gen_add_code_line("if (lane < %d) { s_df_du[lane] = myR[0] + myp[0] + gvec[0] + Lc[0]; }" % n)
@@ -513,18 +522,27 @@ def gen_forward_dynamics_gradient_inner_tip(self, use_thread_group=False, use_qd
     if ts_mode:
         self.gen_add_code_line("grid_pin(myR[0]); grid_pin(myp[0]); grid_pin(gvec[0]);")
     TS(1)
+    _probe(self, "chain", "myR:9", "myp:3", "gvec:3")
     _emit_link_setup(self)
+    _probe(self, "link", "S:6", "I:10")
+    _probe(self, "vel", "v:6", "Pd:6")
     _emit_bias(self, False)
+    _probe(self, "comp_I", "IC:10")
+    _probe(self, "comp_BF", "BC:12", "fC:6", "a:6")
     self.gen_add_code_line("// everything that does not depend on qdd: t1, t2, t4, the bias force; one hand-off record per joint: [S | t1 | t4 | tau - c]")
     self.gen_add_code_line("T t1[6], t2[6], t4[3];")
     self.gen_add_code_line("grid_rbi_mul(t1, IC, S);")
     self.gen_add_code_line("grid_bmul(t2, BC, S); grid_rbi_mul_peq(t2, IC, Pd, static_cast<T>(2));")
     self.gen_add_code_line("grid_btmul(t4, BC, S);")
+    _probe(self, "t1", "t1:6")
+    _probe(self, "t24", "t2:6", "t4:3")
     self.gen_add_code_line("if (lane < %d) {" % n, True)
     self.gen_add_code_line("T *rec = &s_G[16*lane];")
     self.gen_add_code_line("#pragma unroll")
     self.gen_add_code_line("for (int r = 0; r < 6; r++) { rec[r] = S[r]; rec[6 + r] = t1[r]; }")
     self.gen_add_code_line("rec[12] = t4[0]; rec[13] = t4[1]; rec[14] = t4[2]; rec[15] = s_u[lane] - (grid_dot6(S, fC) + Lc[10]*qd);")
+    if "rhs" in tuple(self.tuning.get("round_probe", ())):
+        self.gen_add_code_line("rec[15] = static_cast<T>(static_cast<float>(rec[15]));")
     self.gen_add_end_control_flow()
     self.gen_add_sync(use_thread_group)
     TS(2)
@@ -551,6 +569,8 @@ def gen_forward_dynamics_gradient_inner_tip(self, use_thread_group=False, use_qd
     self.gen_add_code_line("rhs[k] = g[15];")
     self.gen_add_code_line("Mcol[k] = mkj; // (rows k > lane are never read)")
     self.gen_add_end_control_flow()
+    _probe(self, "M", "Mcol:%d" % L)
+    _probe(self, "pass1", "dq:%d" % L, "dqd:%d" % L)
     self.gen_add_code_line("if (lane < %d) {" % n, True)
     self.gen_add_code_line("#pragma unroll")
     self.gen_add_code_line("for (int k = 0; k < %d; k++) { s_M[%d*lane + k] = Mcol[k]; }" % (Lp, ld))
@@ -560,12 +580,17 @@ def gen_forward_dynamics_gradient_inner_tip(self, use_thread_group=False, use_qd
     self.gen_add_code_line("// the joint-space inertia (of this lane's chain), uniform over the chain's lanes: upper triangle A<i>_<j> = M[i][j], i <= j  (column j was written by the lane of joint j)")
     for j in range(L):
         self.gen_add_code_line(" ".join("T A%d_%d = s_M[%d*(base + %d) + %d];" % (i, j, ld, j, i) for i in range(j + 1)))
-    _emit_ldl_factor(self)
+    if "Mread" in tuple(self.tuning.get("round_probe", ())):
+        for j in range(L):
+            self.gen_add_code_line(" ".join("A%d_%d = static_cast<T>(static_cast<float>(A%d_%d));" % (i, j, i, j) for i in range(j + 1)))
+    _emit_ldl_factor(self, probe="factor" in tuple(self.tuning.get("round_probe", ())))
     self.gen_add_code_line("// qdd = M^-1 (tau - c); this lane keeps the entry of its own joint")
     _emit_ldl_solve(self, "rhs")
     sel = "rhs[0]"
     for k in range(1, L):
         sel = "((pos == %d) ? rhs[%d] : %s)" % (k, k, sel)
+    if "qdd" in tuple(self.tuning.get("round_probe", ())):
+        sel = "static_cast<T>(static_cast<float>(%s))" % sel
     self.gen_add_code_line("const T qdd = (lane < %d) ? %s : static_cast<T>(0);" % (n, sel))
     if ts_mode:
         self.gen_add_code_line("{ T qp = qdd; grid_pin(qp); }")
@@ -586,6 +611,7 @@ def gen_forward_dynamics_gradient_inner_tip(self, use_thread_group=False, use_qd
     self.gen_add_end_control_flow()
     self.gen_add_code_line("T Pdd[6]; grid_mxm(Pdd, a, S); grid_mxm_peq(Pdd, v, Pd);")
     self.gen_add_code_line("T t3[6]; grid_bmul(t3, BC, Pd); grid_rbi_mul_peq(t3, IC, Pdd, static_cast<T>(1)); grid_fxv_peq(t3, S, fC);")
+    _probe(self, "t3", "t3:6", "Pdd:6")
     self.gen_add_code_line("// pass 2 over the records: column `lane` of dc/dq")
     self.gen_add_code_line("#pragma unroll")
     self.gen_add_code_line("for (int k = 0; k < %d; k++) {" % L, True)
@@ -596,6 +622,7 @@ def gen_forward_dynamics_gradient_inner_tip(self, use_thread_group=False, use_qd
     self.gen_add_code_line("const T lo_q = g[6]*Pdd[0] + g[7]*Pdd[1] + g[8]*Pdd[2] + g[9]*Pdd[3] + g[10]*Pdd[4] + g[11]*Pdd[5] + dq[k];")
     self.gen_add_code_line("dq[k] = (k <= pos) ? up_q : lo_q;")
     self.gen_add_end_control_flow()
+    _probe(self, "pass2", "dq:%d" % L)
     self.gen_add_code_line("// df/du = -M^-1 dc/du for the two columns this lane owns")
     _emit_ldl_solve(self, "dq")
     _emit_ldl_solve(self, "dqd")

@@ -1,23 +1,50 @@
 // grid_capi.hip - C-ABI shim over the generated, robot-specialised HIP header (see include/grid_capi.h).
 // Built once per robot:  hipcc --offload-arch=gfx950 -O3 -shared -fPIC -I<dir of generated grid.cuh> -I<repo>/include grid_capi.hip
+//
+// Error model: the generated host API follows the reference (gpuAssert prints and exit()s, reference GRiDCodeGenerator.py:279-286).
+// This library must never take the host process down, so it re-binds the header's error hook to a C++ exception that every
+// entry point catches and turns into the hipError_t return value.
+#include <hip/hip_runtime.h>
+
+struct grid_capi_error {
+    hipError_t code;
+    const char *file;
+    int line;
+};
+#define GRID_ON_GPU_ERROR(code, file, line) throw grid_capi_error{(code), (file), (line)}
+
 #include "grid.cuh"
 #include "grid_capi.h"
 
 #include <string.h>
 
+#include <new>
+#include <string>
+#include <thread>
+#include <vector>
+
 #ifndef GRID_ROBOT_NAME
 #define GRID_ROBOT_NAME "robot"
 #endif
+
+template <typename T>
+struct grid_typed {
+    grid::robotModel<T> *d_robotModel = nullptr;
+    grid::gridData<T> *hd_data = nullptr;
+};
 
 struct grid_handle {
     int device;
     int max_timesteps;
     int blocks;   // 0 = derive from the batch
-    int threads;  // 0 = SUGGESTED_THREADS
-    grid::robotModel<float> *d_robotModel;
-    grid::gridData<float> *hd_data;
+    int threads;  // 0 = the kernel's suggested block size
     hipStream_t *streams;
+    grid_typed<float> f32;
+    grid_typed<double> f64;  // allocated by the first *_f64 call
 };
+template <typename T> static inline grid_typed<T> &typed(grid_handle *h);
+template <> inline grid_typed<float> &typed<float>(grid_handle *h) { return h->f32; }
+template <> inline grid_typed<double> &typed<double>(grid_handle *h) { return h->f64; }
 
 static thread_local char g_err[512] = "";
 
@@ -25,42 +52,430 @@ static int fail(hipError_t e, const char *what) {
     snprintf(g_err, sizeof(g_err), "%s: %s", what, hipGetErrorString(e));
     return (int)e;
 }
+static int fail_msg(hipError_t e, const char *msg) {
+    snprintf(g_err, sizeof(g_err), "%s", msg);
+    return (int)e;
+}
 #define GRID_TRY(expr)                                   \
     do {                                                 \
         hipError_t e__ = (expr);                         \
         if (e__ != hipSuccess) return fail(e__, #expr);  \
     } while (0)
+// every entry point body runs inside this: errors raised by the generated host API come back as return codes
+#define GRID_GUARDED(body)                                                                                                       \
+    try {                                                                                                                        \
+        body                                                                                                                     \
+    } catch (const grid_capi_error &e) {                                                                                         \
+        snprintf(g_err, sizeof(g_err), "%s (%s:%d)", hipGetErrorString(e.code), e.file, e.line);                                 \
+        return (int)e.code;                                                                                                      \
+    } catch (const std::exception &e) {                                                                                          \
+        snprintf(g_err, sizeof(g_err), "%s", e.what());                                                                          \
+        return (int)hipErrorUnknown;                                                                                             \
+    }
 
-// dynamic LDS actually needed by a block of `threads` threads: one slice + one staging record per lane group.
-// (the *_DYNAMIC_SHARED_MEM_COUNT constants cover SUGGESTED_THREADS; smaller blocks must not reserve that much or
-//  they lose occupancy: measured 64.8 us vs 22.6 us per 16384-solve launch for 64-thread blocks)
-static inline size_t lds_bytes(const grid_handle *h) {
-    int threads = h->threads > 0 ? h->threads : grid::SUGGESTED_THREADS;
-    int gpb = threads / grid::GRID_LANES_PER_SOLVE;
-    if (gpb > grid::GRID_MAX_SOLVES_PER_BLOCK) gpb = grid::GRID_MAX_SOLVES_PER_BLOCK;
-    if (gpb < 1) gpb = 1;
-    return (size_t)gpb * (grid::GRID_LDS_PER_SOLVE + grid::GRID_OUT_PER_SOLVE) * sizeof(float);
-}
+// Makes the handle's device current for the duration of a call and restores the caller's device afterwards: one process may hold
+// one handle per GPU and call them from any thread in any order (reference: one implicit device, default-stream launches).
+struct device_guard {
+    int prev = -1;
+    bool switched = false;
+    hipError_t err = hipSuccess;
+    explicit device_guard(int dev) {
+        err = hipGetDevice(&prev);
+        if (err == hipSuccess && prev != dev) {
+            err = hipSetDevice(dev);
+            switched = (err == hipSuccess);
+        }
+    }
+    ~device_guard() {
+        if (switched) (void)hipSetDevice(prev);
+    }
+};
+#define GRID_ON_DEVICE(h)                  \
+    device_guard guard__((h)->device);     \
+    if (guard__.err != hipSuccess) return fail(guard__.err, "hipSetDevice(handle device)")
 
-static inline void launch_dims(const grid_handle *h, int num_timesteps, dim3 *grid, dim3 *block) {
-    int threads = h->threads > 0 ? h->threads : grid::SUGGESTED_THREADS;
+static const size_t GRID_CU_LDS_BYTES = 160 * 1024;  // LDS of one gfx950 CU: no block may ask for more
+
+// launch geometry of one kernel: lane groups per block (capped by the kernel's own limit and by the CU's LDS), threads, blocks, LDS bytes
+struct launch_cfg {
+    dim3 grid, block;
+    size_t lds;
+};
+template <typename T>
+static int make_launch(const grid_handle *h, int num_timesteps, int default_threads, int max_groups, int lds_per_solve, int out_per_solve, launch_cfg *cfg) {
+    int threads = h->threads > 0 ? h->threads : default_threads;
+    if (threads < grid::GRID_LANES_PER_SOLVE || threads > grid::GRID_MAX_THREADS)
+        return fail_msg(hipErrorInvalidConfiguration, "threads per block out of range");
     int gpb = threads / grid::GRID_LANES_PER_SOLVE;
-    if (gpb > grid::GRID_MAX_SOLVES_PER_BLOCK) gpb = grid::GRID_MAX_SOLVES_PER_BLOCK;
-    if (gpb < 1) gpb = 1;
+    if (gpb > max_groups) gpb = max_groups;  // (the kernels retire the lane groups beyond their cap)
+    const size_t per_group = (size_t)(lds_per_solve + out_per_solve) * sizeof(T);
+    if ((size_t)gpb * per_group > GRID_CU_LDS_BYTES) {
+        // e.g. the 30-DoF robot in double precision: fewer solves per block than the block size suggests
+        gpb = (int)(GRID_CU_LDS_BYTES / per_group);
+        if (gpb < 1) return fail_msg(hipErrorInvalidConfiguration, "one solve of this robot does not fit the LDS of a CU in this precision");
+        threads = gpb * grid::GRID_LANES_PER_SOLVE;
+    }
     int blocks = h->blocks > 0 ? h->blocks : (num_timesteps + gpb - 1) / gpb;
     if (blocks < 1) blocks = 1;
-    *grid = dim3(blocks, 1, 1);
-    *block = dim3(threads, 1, 1);
+    cfg->grid = dim3(blocks, 1, 1);
+    cfg->block = dim3(threads, 1, 1);
+    cfg->lds = (size_t)gpb * per_group;
+    return 0;
+}
+template <typename T>
+static int general_launch(const grid_handle *h, int num_timesteps, launch_cfg *cfg) {
+    return make_launch<T>(h, num_timesteps, grid::SUGGESTED_THREADS, grid::GRID_MAX_SOLVES_PER_BLOCK, grid::GRID_LDS_PER_SOLVE, grid::GRID_OUT_PER_SOLVE, cfg);
 }
 
 static int check_args(const grid_handle *h, int num_timesteps) {
-    if (!h) { snprintf(g_err, sizeof(g_err), "null handle"); return (int)hipErrorInvalidValue; }
-    if (num_timesteps < 0) { snprintf(g_err, sizeof(g_err), "negative num_timesteps"); return (int)hipErrorInvalidValue; }
-    int threads = h->threads > 0 ? h->threads : grid::SUGGESTED_THREADS;
-    if (threads < grid::GRID_LANES_PER_SOLVE || threads > grid::GRID_MAX_THREADS) {
+    if (!h) return fail_msg(hipErrorInvalidValue, "null handle");
+    if (num_timesteps < 0) return fail_msg(hipErrorInvalidValue, "negative num_timesteps");
+    if (h->threads != 0 && (h->threads < grid::GRID_LANES_PER_SOLVE || h->threads > grid::GRID_MAX_THREADS)) {
         snprintf(g_err, sizeof(g_err), "threads per block must be in [%d, %d]", grid::GRID_LANES_PER_SOLVE, grid::GRID_MAX_THREADS);
         return (int)hipErrorInvalidConfiguration;
     }
+    return 0;
+}
+
+// device + pinned host bytes init_gridData<T>(N) will ask for (same list as the generated function)
+template <typename T>
+static size_t grid_data_bytes(int N) {
+    const size_t n = grid::NUM_JOINTS;
+    size_t per = 3 * n + 2 * n + n + n + n * n + n + 2 * n * n + 2 * n * n;
+#if GRID_HAS_IDSVA_SO
+    per += 8 * n * n * n;
+#endif
+    return per * (size_t)N * sizeof(T);
+}
+
+template <typename T>
+static int ensure_typed(grid_handle *h) {
+    grid_typed<T> &t = typed<T>(h);
+    if (t.hd_data) return 0;
+    size_t free_b = 0, total_b = 0;
+    GRID_TRY(hipMemGetInfo(&free_b, &total_b));
+    if (grid_data_bytes<T>(h->max_timesteps) > free_b) {
+        snprintf(g_err, sizeof(g_err), "grid_init: max_timesteps = %d needs %zu bytes of device memory, %zu are free", h->max_timesteps,
+                 grid_data_bytes<T>(h->max_timesteps), free_b);
+        return (int)hipErrorOutOfMemory;
+    }
+    if (!t.d_robotModel) t.d_robotModel = grid::init_robotModel<T>();
+    t.hd_data = grid::init_gridData<T>(h->max_timesteps);
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------- device entry points
+template <typename T>
+static int fd_grad_device(grid_handle *h, const T *d_q_qd_u, int stride, int N, T gravity, T *d_df_du, void *stream) {
+    int rc = check_args(h, N);
+    if (rc) return rc;
+    if (N == 0) return 0;
+    GRID_ON_DEVICE(h);
+    if ((rc = ensure_typed<T>(h))) return rc;
+    launch_cfg c;
+    // this kernel has its own (smaller) LDS slice and suggested block size: FD_DU_LDS_PER_SOLVE, FD_DU_SUGGESTED_THREADS
+    if ((rc = make_launch<T>(h, N, grid::FD_DU_SUGGESTED_THREADS, grid::GRID_MAX_SOLVES_PER_BLOCK, grid::FD_DU_LDS_PER_SOLVE, grid::GRID_OUT_PER_SOLVE, &c))) return rc;
+    hipLaunchKernelGGL((grid::forward_dynamics_gradient_kernel<T>), c.grid, c.block, c.lds, (hipStream_t)stream, d_df_du, d_q_qd_u, stride,
+                       typed<T>(h).d_robotModel, gravity, N);
+    GRID_TRY(hipGetLastError());
+    return 0;
+}
+
+template <typename T>
+static int fd_grad_qdd_minv_device(grid_handle *h, const T *d_q_qd, int stride, const T *d_qdd, const T *d_Minv, int N, T gravity, T *d_df_du, void *stream) {
+    int rc = check_args(h, N);
+    if (rc) return rc;
+    if (N == 0) return 0;
+    GRID_ON_DEVICE(h);
+    if ((rc = ensure_typed<T>(h))) return rc;
+    launch_cfg c;
+    if ((rc = general_launch<T>(h, N, &c))) return rc;
+    hipLaunchKernelGGL((grid::forward_dynamics_gradient_kernel<T>), c.grid, c.block, c.lds, (hipStream_t)stream, d_df_du, d_q_qd, stride, d_qdd, d_Minv,
+                       typed<T>(h).d_robotModel, gravity, N);
+    GRID_TRY(hipGetLastError());
+    return 0;
+}
+
+template <typename T>
+static int id_device(grid_handle *h, const T *d_q_qd, int stride, const T *d_qdd, int N, T gravity, T *d_c, void *stream) {
+    int rc = check_args(h, N);
+    if (rc) return rc;
+    if (N == 0) return 0;
+    GRID_ON_DEVICE(h);
+    if ((rc = ensure_typed<T>(h))) return rc;
+    launch_cfg c;
+    if ((rc = general_launch<T>(h, N, &c))) return rc;
+    if (d_qdd) {
+        hipLaunchKernelGGL((grid::inverse_dynamics_kernel<T>), c.grid, c.block, c.lds, (hipStream_t)stream, d_c, d_q_qd, stride, d_qdd, typed<T>(h).d_robotModel, gravity, N);
+    } else {
+        hipLaunchKernelGGL((grid::inverse_dynamics_kernel<T>), c.grid, c.block, c.lds, (hipStream_t)stream, d_c, d_q_qd, stride, typed<T>(h).d_robotModel, gravity, N);
+    }
+    GRID_TRY(hipGetLastError());
+    return 0;
+}
+
+template <typename T>
+static int id_grad_device(grid_handle *h, const T *d_q_qd, int stride, const T *d_qdd, int N, T gravity, T *d_dc_du, void *stream) {
+    int rc = check_args(h, N);
+    if (rc) return rc;
+    if (N == 0) return 0;
+    GRID_ON_DEVICE(h);
+    if ((rc = ensure_typed<T>(h))) return rc;
+    launch_cfg c;
+    if ((rc = general_launch<T>(h, N, &c))) return rc;
+    if (d_qdd) {
+        hipLaunchKernelGGL((grid::inverse_dynamics_gradient_kernel<T>), c.grid, c.block, c.lds, (hipStream_t)stream, d_dc_du, d_q_qd, stride, d_qdd,
+                           typed<T>(h).d_robotModel, gravity, N);
+    } else {
+        hipLaunchKernelGGL((grid::inverse_dynamics_gradient_kernel<T>), c.grid, c.block, c.lds, (hipStream_t)stream, d_dc_du, d_q_qd, stride,
+                           typed<T>(h).d_robotModel, gravity, N);
+    }
+    GRID_TRY(hipGetLastError());
+    return 0;
+}
+
+template <typename T>
+static int minv_device(grid_handle *h, const T *d_q, int stride, int N, T *d_Minv, void *stream) {
+    int rc = check_args(h, N);
+    if (rc) return rc;
+    if (N == 0) return 0;
+    GRID_ON_DEVICE(h);
+    if ((rc = ensure_typed<T>(h))) return rc;
+    launch_cfg c;
+    if ((rc = general_launch<T>(h, N, &c))) return rc;
+    hipLaunchKernelGGL((grid::direct_minv_kernel<T>), c.grid, c.block, c.lds, (hipStream_t)stream, d_Minv, d_q, stride, typed<T>(h).d_robotModel, N);
+    GRID_TRY(hipGetLastError());
+    return 0;
+}
+
+template <typename T>
+static int fd_device(grid_handle *h, const T *d_q_qd_u, int stride, int N, T gravity, T *d_qdd, void *stream, bool aba) {
+    int rc = check_args(h, N);
+    if (rc) return rc;
+    if (N == 0) return 0;
+    GRID_ON_DEVICE(h);
+    if ((rc = ensure_typed<T>(h))) return rc;
+    launch_cfg c;
+    if ((rc = general_launch<T>(h, N, &c))) return rc;
+    if (aba) {
+        hipLaunchKernelGGL((grid::aba_kernel<T>), c.grid, c.block, c.lds, (hipStream_t)stream, d_qdd, d_q_qd_u, stride, typed<T>(h).d_robotModel, gravity, N);
+    } else {
+        hipLaunchKernelGGL((grid::forward_dynamics_kernel<T>), c.grid, c.block, c.lds, (hipStream_t)stream, d_qdd, d_q_qd_u, stride, typed<T>(h).d_robotModel, gravity, N);
+    }
+    GRID_TRY(hipGetLastError());
+    return 0;
+}
+
+template <typename T>
+static int idsva_so_device(grid_handle *h, const T *d_q_qd_u, int stride, const T *d_qdd, int N, T gravity, T *d_idsva_so, void *stream) {
+    int rc = check_args(h, N);
+    if (rc) return rc;
+#if GRID_HAS_IDSVA_SO
+    if (N == 0) return 0;
+    GRID_ON_DEVICE(h);
+    if ((rc = ensure_typed<T>(h))) return rc;
+    launch_cfg c;
+    if ((rc = make_launch<T>(h, N, grid::IDSVA_SO_SUGGESTED_THREADS, grid::IDSVA_SO_MAX_SOLVES_PER_BLOCK, grid::IDSVA_SO_LDS_PER_SOLVE, grid::IDSVA_SO_STAGE_PER_SOLVE, &c))) return rc;
+    if (d_qdd) {
+        hipLaunchKernelGGL((grid::idsva_so_kernel<T>), c.grid, c.block, c.lds, (hipStream_t)stream, d_idsva_so, d_q_qd_u, stride, d_qdd, typed<T>(h).d_robotModel, gravity, N);
+    } else {
+        hipLaunchKernelGGL((grid::idsva_so_kernel<T>), c.grid, c.block, c.lds, (hipStream_t)stream, d_idsva_so, d_q_qd_u, stride, typed<T>(h).d_robotModel, gravity, N);
+    }
+    GRID_TRY(hipGetLastError());
+    return 0;
+#else
+    (void)d_q_qd_u; (void)stride; (void)d_qdd; (void)gravity; (void)d_idsva_so; (void)stream;
+    return fail_msg(hipErrorNotSupported, "idsva_so is not emitted for this library's robot (see GRID_HAS_IDSVA_SO in the generated header)");
+#endif
+}
+
+template <typename T>
+static int fdsva_so_device(grid_handle *h, const T *d_q_qd_u, int stride, int N, T gravity, T *d_df2, void *stream) {
+    int rc = check_args(h, N);
+    if (rc) return rc;
+#if GRID_HAS_IDSVA_SO
+    if (N == 0) return 0;
+    GRID_ON_DEVICE(h);
+    if ((rc = ensure_typed<T>(h))) return rc;
+    launch_cfg c;
+    if ((rc = make_launch<T>(h, N, grid::FDSVA_SO_SUGGESTED_THREADS, grid::FDSVA_SO_MAX_SOLVES_PER_BLOCK, grid::GRID_LDS_PER_SOLVE, grid::FDSVA_SO_STAGE_PER_SOLVE, &c))) return rc;
+    hipLaunchKernelGGL((grid::fdsva_so_kernel<T>), c.grid, c.block, c.lds, (hipStream_t)stream, d_df2, d_q_qd_u, stride, typed<T>(h).d_robotModel, gravity, N);
+    GRID_TRY(hipGetLastError());
+    return 0;
+#else
+    (void)d_q_qd_u; (void)stride; (void)gravity; (void)d_df2; (void)stream;
+    return fail_msg(hipErrorNotSupported, "fdsva_so is not emitted for this library's robot (see GRID_HAS_IDSVA_SO in the generated header)");
+#endif
+}
+
+// ---------------------------------------------------------------------------------------------------------------- host entry points
+// Host buffers in, host buffers out, synchronous: H2D on the handle's stream, launch, D2H, stream sync - the semantics of the
+// reference's host wrappers (e.g. reference algorithms/_inverse_dynamics.py:440-512), with the handle's device buffers as staging.
+template <typename T>
+static int host_prologue(grid_handle *h, int N) {
+    int rc = check_args(h, N);
+    if (rc) return rc;
+    if (N > h->max_timesteps) return fail_msg(hipErrorInvalidValue, "num_timesteps exceeds grid_init's max_timesteps");
+    return 0;
+}
+#define GRID_H2D(dst, src, count) GRID_TRY(hipMemcpyAsync((dst), (src), (size_t)(count) * sizeof(T), hipMemcpyHostToDevice, s))
+#define GRID_D2H(dst, src, count) GRID_TRY(hipMemcpyAsync((dst), (src), (size_t)(count) * sizeof(T), hipMemcpyDeviceToHost, s))
+
+template <typename T>
+static int fd_grad_host(grid_handle *h, const T *h_q_qd_u, int N, T gravity, T *h_df_du) {
+    int rc = host_prologue<T>(h, N);
+    if (rc || N == 0) return rc;
+    GRID_ON_DEVICE(h);
+    if ((rc = ensure_typed<T>(h))) return rc;
+    const size_t n = grid::NUM_JOINTS;
+    grid::gridData<T> *d = typed<T>(h).hd_data;
+    hipStream_t s = h->streams[0];
+    GRID_H2D(d->d_q_qd_u, h_q_qd_u, 3 * n * N);
+    if ((rc = fd_grad_device<T>(h, d->d_q_qd_u, 3 * (int)n, N, gravity, d->d_df_du, (void *)s))) return rc;
+    GRID_D2H(h_df_du, d->d_df_du, 2 * n * n * N);
+    GRID_TRY(hipStreamSynchronize(s));
+    return 0;
+}
+
+template <typename T>
+static int fd_grad_qdd_minv_host(grid_handle *h, const T *h_q_qd, int stride, const T *h_qdd, const T *h_Minv, int N, T gravity, T *h_df_du) {
+    int rc = host_prologue<T>(h, N);
+    if (rc || N == 0) return rc;
+    const size_t n = grid::NUM_JOINTS;
+    if (stride < 2 * (int)n || stride > 3 * (int)n) return fail_msg(hipErrorInvalidValue, "stride must be in [2n, 3n] for host buffers");
+    GRID_ON_DEVICE(h);
+    if ((rc = ensure_typed<T>(h))) return rc;
+    grid::gridData<T> *d = typed<T>(h).hd_data;
+    hipStream_t s = h->streams[0];
+    GRID_H2D(d->d_q_qd_u, h_q_qd, (size_t)stride * N);
+    GRID_H2D(d->d_qdd, h_qdd, n * N);
+    GRID_H2D(d->d_Minv, h_Minv, n * n * N);
+    if ((rc = fd_grad_qdd_minv_device<T>(h, d->d_q_qd_u, stride, d->d_qdd, d->d_Minv, N, gravity, d->d_df_du, (void *)s))) return rc;
+    GRID_D2H(h_df_du, d->d_df_du, 2 * n * n * N);
+    GRID_TRY(hipStreamSynchronize(s));
+    return 0;
+}
+
+// which: 0 = inverse dynamics (c), 1 = its gradient (dc_du)
+template <typename T>
+static int id_host(grid_handle *h, const T *h_q_qd, int stride, const T *h_qdd, int N, T gravity, T *h_out, int which) {
+    int rc = host_prologue<T>(h, N);
+    if (rc || N == 0) return rc;
+    const size_t n = grid::NUM_JOINTS;
+    if (stride < 2 * (int)n || stride > 3 * (int)n) return fail_msg(hipErrorInvalidValue, "stride must be in [2n, 3n] for host buffers (USE_COMPRESSED_MEM: 2n)");
+    GRID_ON_DEVICE(h);
+    if ((rc = ensure_typed<T>(h))) return rc;
+    grid::gridData<T> *d = typed<T>(h).hd_data;
+    hipStream_t s = h->streams[0];
+    GRID_H2D(d->d_q_qd_u, h_q_qd, (size_t)stride * N);
+    if (h_qdd) GRID_H2D(d->d_qdd, h_qdd, n * N);
+    if (which == 0) {
+        if ((rc = id_device<T>(h, d->d_q_qd_u, stride, h_qdd ? d->d_qdd : nullptr, N, gravity, d->d_c, (void *)s))) return rc;
+        GRID_D2H(h_out, d->d_c, n * N);
+    } else {
+        if ((rc = id_grad_device<T>(h, d->d_q_qd_u, stride, h_qdd ? d->d_qdd : nullptr, N, gravity, d->d_dc_du, (void *)s))) return rc;
+        GRID_D2H(h_out, d->d_dc_du, 2 * n * n * N);
+    }
+    GRID_TRY(hipStreamSynchronize(s));
+    return 0;
+}
+
+template <typename T>
+static int minv_host(grid_handle *h, const T *h_q, int stride, int N, T *h_Minv) {
+    int rc = host_prologue<T>(h, N);
+    if (rc || N == 0) return rc;
+    const size_t n = grid::NUM_JOINTS;
+    if (stride < (int)n || stride > 3 * (int)n) return fail_msg(hipErrorInvalidValue, "stride must be in [n, 3n] for host buffers (USE_COMPRESSED_MEM: n)");
+    GRID_ON_DEVICE(h);
+    if ((rc = ensure_typed<T>(h))) return rc;
+    grid::gridData<T> *d = typed<T>(h).hd_data;
+    hipStream_t s = h->streams[0];
+    GRID_H2D(d->d_q_qd_u, h_q, (size_t)stride * N);
+    if ((rc = minv_device<T>(h, d->d_q_qd_u, stride, N, d->d_Minv, (void *)s))) return rc;
+    GRID_D2H(h_Minv, d->d_Minv, n * n * N);
+    GRID_TRY(hipStreamSynchronize(s));
+    return 0;
+}
+
+template <typename T>
+static int fd_host(grid_handle *h, const T *h_q_qd_u, int N, T gravity, T *h_qdd, bool aba) {
+    int rc = host_prologue<T>(h, N);
+    if (rc || N == 0) return rc;
+    const size_t n = grid::NUM_JOINTS;
+    GRID_ON_DEVICE(h);
+    if ((rc = ensure_typed<T>(h))) return rc;
+    grid::gridData<T> *d = typed<T>(h).hd_data;
+    hipStream_t s = h->streams[0];
+    GRID_H2D(d->d_q_qd_u, h_q_qd_u, 3 * n * N);
+    if ((rc = fd_device<T>(h, d->d_q_qd_u, 3 * (int)n, N, gravity, d->d_qdd, (void *)s, aba))) return rc;
+    GRID_D2H(h_qdd, d->d_qdd, n * N);
+    GRID_TRY(hipStreamSynchronize(s));
+    return 0;
+}
+
+// which: 0 = idsva_so (h_qdd may be NULL), 1 = fdsva_so
+template <typename T>
+static int so_host(grid_handle *h, const T *h_q_qd_u, const T *h_qdd, int N, T gravity, T *h_out, int which) {
+    int rc = host_prologue<T>(h, N);
+    if (rc) return rc;
+#if GRID_HAS_IDSVA_SO
+    if (N == 0) return 0;
+    const size_t n = grid::NUM_JOINTS;
+    GRID_ON_DEVICE(h);
+    if ((rc = ensure_typed<T>(h))) return rc;
+    grid::gridData<T> *d = typed<T>(h).hd_data;
+    hipStream_t s = h->streams[0];
+    GRID_H2D(d->d_q_qd_u, h_q_qd_u, 3 * n * N);
+    if (which == 0) {
+        if (h_qdd) GRID_H2D(d->d_qdd, h_qdd, n * N);
+        if ((rc = idsva_so_device<T>(h, d->d_q_qd_u, 3 * (int)n, h_qdd ? d->d_qdd : nullptr, N, gravity, d->d_idsva_so, (void *)s))) return rc;
+        GRID_D2H(h_out, d->d_idsva_so, 4 * n * n * n * N);
+    } else {
+        if ((rc = fdsva_so_device<T>(h, d->d_q_qd_u, 3 * (int)n, N, gravity, d->d_df2, (void *)s))) return rc;
+        GRID_D2H(h_out, d->d_df2, 4 * n * n * n * N);
+    }
+    GRID_TRY(hipStreamSynchronize(s));
+    return 0;
+#else
+    (void)h_q_qd_u; (void)h_qdd; (void)gravity; (void)h_out; (void)which;
+    return fail_msg(hipErrorNotSupported, "the second-order kernels are not emitted for this library's robot (see GRID_HAS_IDSVA_SO in the generated header)");
+#endif
+}
+
+// ---------------------------------------------------------------------------------------------------------------- multi-GPU driver
+// One process, G handles (one per GPU): the batch [0, N) is cut into G contiguous ranges of ceil(N/G) solves (SURVEY.md section 8(e),
+// 16 384 total -> 16 384/G per GPU, no collective).  Every device has its own robotModel copy and stream.
+static inline void multi_range(int N, int G, int g, int *k0, int *cnt) {
+    const int per = (N + G - 1) / G;
+    int a = g * per, b = a + per;
+    if (a > N) a = N;
+    if (b > N) b = N;
+    *k0 = a;
+    *cnt = b - a;
+}
+
+template <typename T>
+static int fd_grad_multi_host(grid_handle **hs, int G, const T *h_q_qd_u, int N, T gravity, T *h_df_du) {
+    if (!hs || G < 1 || N < 0) return fail_msg(hipErrorInvalidValue, "grid_forward_dynamics_gradient_multi_host: bad arguments");
+    const size_t n = grid::NUM_JOINTS;
+    std::vector<int> rcs(G, 0);
+    std::vector<std::string> msgs(G);
+    std::vector<std::thread> ts;
+    // one host thread per device: pageable host memory makes hipMemcpyAsync block, threads keep the G copy engines busy at once
+    for (int g = 0; g < G; g++) {
+        ts.emplace_back([&, g]() {
+            int k0, cnt;
+            multi_range(N, G, g, &k0, &cnt);
+            rcs[g] = fd_grad_host<T>(hs[g], h_q_qd_u + (size_t)k0 * 3 * n, cnt, gravity, h_df_du + (size_t)k0 * 2 * n * n);
+            if (rcs[g]) msgs[g] = g_err;  // (g_err is thread-local)
+        });
+    }
+    for (auto &t : ts) t.join();
+    for (int g = 0; g < G; g++)
+        if (rcs[g]) {
+            snprintf(g_err, sizeof(g_err), "device slot %d: %s", g, msgs[g].c_str());
+            return rcs[g];
+        }
     return 0;
 }
 
@@ -71,222 +486,150 @@ const char *grid_robot_name(void) { return GRID_ROBOT_NAME; }
 int grid_lanes_per_solve(void) { return grid::GRID_LANES_PER_SOLVE; }
 int grid_suggested_threads(void) { return grid::SUGGESTED_THREADS; }
 int grid_lds_bytes_per_block(void) { return grid::FD_DU_DYNAMIC_SHARED_MEM_COUNT * (int)sizeof(float); }
+int grid_has_second_order(void) { return GRID_HAS_IDSVA_SO; }
 const char *grid_last_error(void) { return g_err; }
 
 int grid_init(int device, int max_timesteps, grid_handle **out) {
-    if (!out || max_timesteps < 1) { snprintf(g_err, sizeof(g_err), "grid_init: bad arguments"); return (int)hipErrorInvalidValue; }
-    GRID_TRY(hipSetDevice(device));
-    grid_handle *h = (grid_handle *)calloc(1, sizeof(grid_handle));
+    if (!out || max_timesteps < 1) return fail_msg(hipErrorInvalidValue, "grid_init: bad arguments");
+    *out = nullptr;
+    device_guard guard(device);
+    if (guard.err != hipSuccess) return fail(guard.err, "hipSetDevice(device)");
+    grid_handle *h = new (std::nothrow) grid_handle();
+    if (!h) return fail_msg(hipErrorOutOfMemory, "grid_init: out of host memory");
     h->device = device;
     h->max_timesteps = max_timesteps;
-    h->d_robotModel = grid::init_robotModel<float>();
-    h->streams = grid::init_grid<float>();
-    h->hd_data = grid::init_gridData<float>(max_timesteps);
+    h->blocks = h->threads = 0;
+    h->streams = nullptr;
+    int rc = 0;
+    try {
+        rc = ensure_typed<float>(h);
+        if (!rc) h->streams = grid::init_grid<float>();
+    } catch (const grid_capi_error &e) {
+        snprintf(g_err, sizeof(g_err), "grid_init: %s (%s:%d)", hipGetErrorString(e.code), e.file, e.line);
+        rc = (int)e.code;
+    }
+    if (rc) {  // (buffers a failed init_* allocated before the failing call are not tracked: they stay allocated until the process ends)
+        delete h;
+        return rc;
+    }
     *out = h;
     return 0;
 }
 
 int grid_close(grid_handle *h) {
     if (!h) return 0;
-    GRID_TRY(hipSetDevice(h->device));
-    grid::close_grid<float>(h->streams, h->d_robotModel, h->hd_data);
-    free(h);
+    GRID_ON_DEVICE(h);
+    GRID_GUARDED(
+        if (h->f64.hd_data) {  // close_grid frees the streams too: give the f64 state its own (empty) set
+            hipStream_t *none = grid::init_grid<double>();
+            grid::close_grid<double>(none, h->f64.d_robotModel, h->f64.hd_data);
+        }
+        grid::close_grid<float>(h->streams, h->f32.d_robotModel, h->f32.hd_data);
+    )
+    delete h;
     return 0;
 }
+
+int grid_device(const grid_handle *h) { return h ? h->device : -1; }
 
 int grid_set_launch_dims(grid_handle *h, int blocks, int threads) {
     if (!h) return (int)hipErrorInvalidValue;
+    if (blocks < 0 || (threads != 0 && (threads < grid::GRID_LANES_PER_SOLVE || threads > grid::GRID_MAX_THREADS))) {
+        snprintf(g_err, sizeof(g_err), "threads per block must be 0 or in [%d, %d], blocks >= 0", grid::GRID_LANES_PER_SOLVE, grid::GRID_MAX_THREADS);
+        return (int)hipErrorInvalidConfiguration;
+    }
     h->blocks = blocks;
     h->threads = threads;
-    return check_args(h, 0);
-}
-
-int grid_forward_dynamics_gradient_device(grid_handle *h, const float *d_q_qd_u, int stride_q_qd_u, int num_timesteps, float gravity,
-                                          float *d_df_du, void *stream) {
-    int rc = check_args(h, num_timesteps);
-    if (rc) return rc;
-    if (num_timesteps == 0) return 0;
-    // this kernel has its own (smaller) LDS slice and suggested block size: FD_DU_LDS_PER_SOLVE, FD_DU_SUGGESTED_THREADS
-    int threads = h->threads > 0 ? h->threads : grid::FD_DU_SUGGESTED_THREADS;
-    int gpb = threads / grid::GRID_LANES_PER_SOLVE;
-    if (gpb > grid::GRID_MAX_SOLVES_PER_BLOCK) gpb = grid::GRID_MAX_SOLVES_PER_BLOCK;
-    if (gpb < 1) gpb = 1;
-    int blocks = h->blocks > 0 ? h->blocks : (num_timesteps + gpb - 1) / gpb;
-    const dim3 grid(blocks < 1 ? 1 : blocks, 1, 1), block(threads, 1, 1);
-    hipLaunchKernelGGL((grid::forward_dynamics_gradient_kernel<float>), grid, block, (size_t)gpb * (grid::FD_DU_LDS_PER_SOLVE + grid::GRID_OUT_PER_SOLVE) * sizeof(float),
-                       (hipStream_t)stream, d_df_du, d_q_qd_u, stride_q_qd_u, h->d_robotModel, gravity, num_timesteps);
-    GRID_TRY(hipGetLastError());
     return 0;
 }
 
+// ---- float
+int grid_forward_dynamics_gradient_device(grid_handle *h, const float *d_q_qd_u, int stride_q_qd_u, int num_timesteps, float gravity, float *d_df_du, void *stream) {
+    GRID_GUARDED(return fd_grad_device<float>(h, d_q_qd_u, stride_q_qd_u, num_timesteps, gravity, d_df_du, stream);)
+}
 int grid_forward_dynamics_gradient_qdd_minv_device(grid_handle *h, const float *d_q_qd, int stride_q_qd, const float *d_qdd, const float *d_Minv,
                                                    int num_timesteps, float gravity, float *d_df_du, void *stream) {
-    int rc = check_args(h, num_timesteps);
-    if (rc) return rc;
-    if (num_timesteps == 0) return 0;
-    dim3 grid, block;
-    launch_dims(h, num_timesteps, &grid, &block);
-    hipLaunchKernelGGL((grid::forward_dynamics_gradient_kernel<float>), grid, block, lds_bytes(h),
-                       (hipStream_t)stream, d_df_du, d_q_qd, stride_q_qd, d_qdd, d_Minv, h->d_robotModel, gravity, num_timesteps);
-    GRID_TRY(hipGetLastError());
-    return 0;
+    GRID_GUARDED(return fd_grad_qdd_minv_device<float>(h, d_q_qd, stride_q_qd, d_qdd, d_Minv, num_timesteps, gravity, d_df_du, stream);)
+}
+int grid_inverse_dynamics_device(grid_handle *h, const float *d_q_qd, int stride_q_qd, const float *d_qdd, int num_timesteps, float gravity, float *d_c, void *stream) {
+    GRID_GUARDED(return id_device<float>(h, d_q_qd, stride_q_qd, d_qdd, num_timesteps, gravity, d_c, stream);)
+}
+int grid_inverse_dynamics_gradient_device(grid_handle *h, const float *d_q_qd, int stride_q_qd, const float *d_qdd, int num_timesteps, float gravity,
+                                          float *d_dc_du, void *stream) {
+    GRID_GUARDED(return id_grad_device<float>(h, d_q_qd, stride_q_qd, d_qdd, num_timesteps, gravity, d_dc_du, stream);)
+}
+int grid_direct_minv_device(grid_handle *h, const float *d_q, int stride_q, int num_timesteps, float *d_Minv, void *stream) {
+    GRID_GUARDED(return minv_device<float>(h, d_q, stride_q, num_timesteps, d_Minv, stream);)
+}
+int grid_forward_dynamics_device(grid_handle *h, const float *d_q_qd_u, int stride_q_qd_u, int num_timesteps, float gravity, float *d_qdd, void *stream) {
+    GRID_GUARDED(return fd_device<float>(h, d_q_qd_u, stride_q_qd_u, num_timesteps, gravity, d_qdd, stream, false);)
+}
+int grid_aba_device(grid_handle *h, const float *d_q_qd_tau, int stride_q_qd, int num_timesteps, float gravity, float *d_qdd, void *stream) {
+    GRID_GUARDED(return fd_device<float>(h, d_q_qd_tau, stride_q_qd, num_timesteps, gravity, d_qdd, stream, true);)
+}
+int grid_idsva_so_device(grid_handle *h, const float *d_q_qd_u, int stride_q_qd_u, const float *d_qdd, int num_timesteps, float gravity, float *d_idsva_so, void *stream) {
+    GRID_GUARDED(return idsva_so_device<float>(h, d_q_qd_u, stride_q_qd_u, d_qdd, num_timesteps, gravity, d_idsva_so, stream);)
+}
+int grid_fdsva_so_device(grid_handle *h, const float *d_q_qd_u, int stride_q_qd_u, int num_timesteps, float gravity, float *d_df2, void *stream) {
+    GRID_GUARDED(return fdsva_so_device<float>(h, d_q_qd_u, stride_q_qd_u, num_timesteps, gravity, d_df2, stream);)
 }
 
 int grid_forward_dynamics_gradient_host(grid_handle *h, const float *h_q_qd_u, int num_timesteps, float gravity, float *h_df_du) {
-    int rc = check_args(h, num_timesteps);
-    if (rc) return rc;
-    if (num_timesteps > h->max_timesteps) { snprintf(g_err, sizeof(g_err), "num_timesteps exceeds grid_init's max_timesteps"); return (int)hipErrorInvalidValue; }
-    if (num_timesteps == 0) return 0;
-    const int n = grid::NUM_JOINTS;
-    GRID_TRY(hipSetDevice(h->device));
-    hipStream_t s = h->streams[0];
-    GRID_TRY(hipMemcpyAsync(h->hd_data->d_q_qd_u, h_q_qd_u, (size_t)3 * n * num_timesteps * sizeof(float), hipMemcpyHostToDevice, s));
-    rc = grid_forward_dynamics_gradient_device(h, h->hd_data->d_q_qd_u, 3 * n, num_timesteps, gravity, h->hd_data->d_df_du, (void *)s);
-    if (rc) return rc;
-    GRID_TRY(hipMemcpyAsync(h_df_du, h->hd_data->d_df_du, (size_t)2 * n * n * num_timesteps * sizeof(float), hipMemcpyDeviceToHost, s));
-    GRID_TRY(hipStreamSynchronize(s));
-    return 0;
+    GRID_GUARDED(return fd_grad_host<float>(h, h_q_qd_u, num_timesteps, gravity, h_df_du);)
+}
+int grid_forward_dynamics_gradient_qdd_minv_host(grid_handle *h, const float *h_q_qd, int stride_q_qd, const float *h_qdd, const float *h_Minv, int num_timesteps,
+                                                 float gravity, float *h_df_du) {
+    GRID_GUARDED(return fd_grad_qdd_minv_host<float>(h, h_q_qd, stride_q_qd, h_qdd, h_Minv, num_timesteps, gravity, h_df_du);)
+}
+int grid_inverse_dynamics_host(grid_handle *h, const float *h_q_qd, int stride_q_qd, const float *h_qdd, int num_timesteps, float gravity, float *h_c) {
+    GRID_GUARDED(return id_host<float>(h, h_q_qd, stride_q_qd, h_qdd, num_timesteps, gravity, h_c, 0);)
+}
+int grid_inverse_dynamics_gradient_host(grid_handle *h, const float *h_q_qd, int stride_q_qd, const float *h_qdd, int num_timesteps, float gravity, float *h_dc_du) {
+    GRID_GUARDED(return id_host<float>(h, h_q_qd, stride_q_qd, h_qdd, num_timesteps, gravity, h_dc_du, 1);)
+}
+int grid_direct_minv_host(grid_handle *h, const float *h_q, int stride_q, int num_timesteps, float *h_Minv) {
+    GRID_GUARDED(return minv_host<float>(h, h_q, stride_q, num_timesteps, h_Minv);)
+}
+int grid_forward_dynamics_host(grid_handle *h, const float *h_q_qd_u, int num_timesteps, float gravity, float *h_qdd) {
+    GRID_GUARDED(return fd_host<float>(h, h_q_qd_u, num_timesteps, gravity, h_qdd, false);)
+}
+int grid_aba_host(grid_handle *h, const float *h_q_qd_tau, int num_timesteps, float gravity, float *h_qdd) {
+    GRID_GUARDED(return fd_host<float>(h, h_q_qd_tau, num_timesteps, gravity, h_qdd, true);)
+}
+int grid_idsva_so_host(grid_handle *h, const float *h_q_qd_u, const float *h_qdd, int num_timesteps, float gravity, float *h_idsva_so) {
+    GRID_GUARDED(return so_host<float>(h, h_q_qd_u, h_qdd, num_timesteps, gravity, h_idsva_so, 0);)
+}
+int grid_fdsva_so_host(grid_handle *h, const float *h_q_qd_u, int num_timesteps, float gravity, float *h_df2) {
+    GRID_GUARDED(return so_host<float>(h, h_q_qd_u, nullptr, num_timesteps, gravity, h_df2, 1);)
+}
+int grid_forward_dynamics_gradient_multi_host(grid_handle **handles, int num_handles, const float *h_q_qd_u, int num_timesteps, float gravity, float *h_df_du) {
+    GRID_GUARDED(return fd_grad_multi_host<float>(handles, num_handles, h_q_qd_u, num_timesteps, gravity, h_df_du);)
 }
 
-int grid_inverse_dynamics_device(grid_handle *h, const float *d_q_qd, int stride_q_qd, const float *d_qdd, int num_timesteps, float gravity,
-                                 float *d_c, void *stream) {
-    int rc = check_args(h, num_timesteps);
-    if (rc) return rc;
-    if (num_timesteps == 0) return 0;
-    dim3 grid, block;
-    launch_dims(h, num_timesteps, &grid, &block);
-    if (d_qdd) {
-        hipLaunchKernelGGL((grid::inverse_dynamics_kernel<float>), grid, block, lds_bytes(h), (hipStream_t)stream,
-                           d_c, d_q_qd, stride_q_qd, d_qdd, h->d_robotModel, gravity, num_timesteps);
-    } else {
-        hipLaunchKernelGGL((grid::inverse_dynamics_kernel<float>), grid, block, lds_bytes(h), (hipStream_t)stream,
-                           d_c, d_q_qd, stride_q_qd, h->d_robotModel, gravity, num_timesteps);
-    }
-    GRID_TRY(hipGetLastError());
-    return 0;
+// ---- double (the hot path and its host form; T = double instantiations of the same generated kernels)
+int grid_forward_dynamics_gradient_device_f64(grid_handle *h, const double *d_q_qd_u, int stride_q_qd_u, int num_timesteps, double gravity, double *d_df_du, void *stream) {
+    GRID_GUARDED(return fd_grad_device<double>(h, d_q_qd_u, stride_q_qd_u, num_timesteps, gravity, d_df_du, stream);)
 }
-
-int grid_direct_minv_device(grid_handle *h, const float *d_q, int stride_q, int num_timesteps, float *d_Minv, void *stream) {
-    int rc = check_args(h, num_timesteps);
-    if (rc) return rc;
-    if (num_timesteps == 0) return 0;
-    dim3 grid, block;
-    launch_dims(h, num_timesteps, &grid, &block);
-    hipLaunchKernelGGL((grid::direct_minv_kernel<float>), grid, block, lds_bytes(h), (hipStream_t)stream,
-                       d_Minv, d_q, stride_q, h->d_robotModel, num_timesteps);
-    GRID_TRY(hipGetLastError());
-    return 0;
-}
-
-int grid_forward_dynamics_device(grid_handle *h, const float *d_q_qd_u, int stride_q_qd_u, int num_timesteps, float gravity, float *d_qdd, void *stream) {
-    int rc = check_args(h, num_timesteps);
-    if (rc) return rc;
-    if (num_timesteps == 0) return 0;
-    dim3 grid, block;
-    launch_dims(h, num_timesteps, &grid, &block);
-    hipLaunchKernelGGL((grid::forward_dynamics_kernel<float>), grid, block, lds_bytes(h), (hipStream_t)stream,
-                       d_qdd, d_q_qd_u, stride_q_qd_u, h->d_robotModel, gravity, num_timesteps);
-    GRID_TRY(hipGetLastError());
-    return 0;
-}
-
-int grid_aba_device(grid_handle *h, const float *d_q_qd_tau, int stride_q_qd, int num_timesteps, float gravity, float *d_qdd, void *stream) {
-    int rc = check_args(h, num_timesteps);
-    if (rc) return rc;
-    if (num_timesteps == 0) return 0;
-    dim3 grid, block;
-    launch_dims(h, num_timesteps, &grid, &block);
-    hipLaunchKernelGGL((grid::aba_kernel<float>), grid, block, lds_bytes(h), (hipStream_t)stream,
-                       d_qdd, d_q_qd_tau, stride_q_qd, h->d_robotModel, gravity, num_timesteps);
-    GRID_TRY(hipGetLastError());
-    return 0;
-}
-
-int grid_idsva_so_device(grid_handle *h, const float *d_q_qd_u, int stride_q_qd_u, const float *d_qdd, int num_timesteps, float gravity,
-                         float *d_idsva_so, void *stream) {
-    int rc = check_args(h, num_timesteps);
-    if (rc) return rc;
-#if GRID_HAS_IDSVA_SO
-    if (num_timesteps == 0) return 0;
-    int threads = h->threads > 0 ? h->threads : grid::IDSVA_SO_SUGGESTED_THREADS;
-    if (threads > grid::IDSVA_SO_SUGGESTED_THREADS) threads = grid::IDSVA_SO_SUGGESTED_THREADS;
-    int gpb = threads / grid::GRID_LANES_PER_SOLVE;
-    if (gpb < 1) { gpb = 1; threads = grid::GRID_LANES_PER_SOLVE; }
-    const int blocks = h->blocks > 0 ? h->blocks : (num_timesteps + gpb - 1) / gpb;
-    const size_t lds = (size_t)gpb * (grid::IDSVA_SO_LDS_PER_SOLVE + grid::IDSVA_SO_STAGE_PER_SOLVE) * sizeof(float);
-    const dim3 grid(blocks, 1, 1), block(threads, 1, 1);
-    if (d_qdd) {
-        hipLaunchKernelGGL((grid::idsva_so_kernel<float>), grid, block, lds, (hipStream_t)stream,
-                           d_idsva_so, d_q_qd_u, stride_q_qd_u, d_qdd, h->d_robotModel, gravity, num_timesteps);
-    } else {
-        hipLaunchKernelGGL((grid::idsva_so_kernel<float>), grid, block, lds, (hipStream_t)stream,
-                           d_idsva_so, d_q_qd_u, stride_q_qd_u, h->d_robotModel, gravity, num_timesteps);
-    }
-    GRID_TRY(hipGetLastError());
-    return 0;
-#else
-    (void)d_q_qd_u; (void)stride_q_qd_u; (void)d_qdd; (void)gravity; (void)d_idsva_so; (void)stream;
-    snprintf(g_err, sizeof(g_err), "idsva_so is emitted for serial revolute chains only; this library's robot is not one");
-    return (int)hipErrorNotSupported;
-#endif
-}
-
-int grid_fdsva_so_device(grid_handle *h, const float *d_q_qd_u, int stride_q_qd_u, int num_timesteps, float gravity, float *d_df2, void *stream) {
-    int rc = check_args(h, num_timesteps);
-    if (rc) return rc;
-#if GRID_HAS_IDSVA_SO
-    if (num_timesteps == 0) return 0;
-    int threads = h->threads > 0 ? h->threads : grid::FDSVA_SO_SUGGESTED_THREADS;
-    if (threads > grid::FDSVA_SO_SUGGESTED_THREADS) threads = grid::FDSVA_SO_SUGGESTED_THREADS;
-    int gpb = threads / grid::GRID_LANES_PER_SOLVE;
-    if (gpb < 1) { gpb = 1; threads = grid::GRID_LANES_PER_SOLVE; }
-    int blocks = h->blocks > 0 ? h->blocks : (num_timesteps + gpb - 1) / gpb;
-    const size_t lds = (size_t)gpb * (grid::GRID_LDS_PER_SOLVE + grid::FDSVA_SO_STAGE_PER_SOLVE) * sizeof(float);
-    hipLaunchKernelGGL((grid::fdsva_so_kernel<float>), dim3(blocks, 1, 1), dim3(threads, 1, 1), lds, (hipStream_t)stream,
-                       d_df2, d_q_qd_u, stride_q_qd_u, h->d_robotModel, gravity, num_timesteps);
-    GRID_TRY(hipGetLastError());
-    return 0;
-#else
-    (void)d_q_qd_u; (void)stride_q_qd_u; (void)gravity; (void)d_df2; (void)stream;
-    snprintf(g_err, sizeof(g_err), "fdsva_so is emitted for serial revolute chains only; this library's robot is not one");
-    return (int)hipErrorNotSupported;
-#endif
-}
-
-int grid_inverse_dynamics_gradient_device(grid_handle *h, const float *d_q_qd, int stride_q_qd, const float *d_qdd, int num_timesteps, float gravity,
-                                          float *d_dc_du, void *stream) {
-    int rc = check_args(h, num_timesteps);
-    if (rc) return rc;
-    if (num_timesteps == 0) return 0;
-    dim3 grid, block;
-    launch_dims(h, num_timesteps, &grid, &block);
-    if (d_qdd) {
-        hipLaunchKernelGGL((grid::inverse_dynamics_gradient_kernel<float>), grid, block, lds_bytes(h),
-                           (hipStream_t)stream, d_dc_du, d_q_qd, stride_q_qd, d_qdd, h->d_robotModel, gravity, num_timesteps);
-    } else {
-        hipLaunchKernelGGL((grid::inverse_dynamics_gradient_kernel<float>), grid, block, lds_bytes(h),
-                           (hipStream_t)stream, d_dc_du, d_q_qd, stride_q_qd, h->d_robotModel, gravity, num_timesteps);
-    }
-    GRID_TRY(hipGetLastError());
-    return 0;
+int grid_forward_dynamics_gradient_host_f64(grid_handle *h, const double *h_q_qd_u, int num_timesteps, double gravity, double *h_df_du) {
+    GRID_GUARDED(return fd_grad_host<double>(h, h_q_qd_u, num_timesteps, gravity, h_df_du);)
 }
 
 int grid_forward_dynamics_gradient_single_timing(grid_handle *h, const float *h_q_qd_u, int reps, float gravity, float *h_df_du, double *us_per_call) {
     int rc = check_args(h, reps);
     if (rc) return rc;
     const int n = grid::NUM_JOINTS;
-    GRID_TRY(hipSetDevice(h->device));
-    GRID_TRY(hipMemcpy(h->hd_data->d_q_qd_u, h_q_qd_u, (size_t)3 * n * sizeof(float), hipMemcpyHostToDevice));
+    GRID_ON_DEVICE(h);
+    GRID_TRY(hipMemcpy(h->f32.hd_data->d_q_qd_u, h_q_qd_u, (size_t)3 * n * sizeof(float), hipMemcpyHostToDevice));
     GRID_TRY(hipDeviceSynchronize());
     struct timespec start, end;
     clock_gettime(CLOCK_MONOTONIC, &start);
     hipLaunchKernelGGL((grid::forward_dynamics_gradient_kernel_single_timing<float>), dim3(1), dim3(grid::GRID_LANES_PER_SOLVE < 64 ? 64 : grid::GRID_LANES_PER_SOLVE),
                        (size_t)(64 / grid::GRID_LANES_PER_SOLVE > 0 ? 64 / grid::GRID_LANES_PER_SOLVE : 1) * (grid::GRID_LDS_PER_SOLVE + grid::GRID_OUT_PER_SOLVE) * sizeof(float),
-                       0, h->hd_data->d_df_du, h->hd_data->d_q_qd_u, 3 * n, h->d_robotModel, gravity, reps);
+                       0, h->f32.hd_data->d_df_du, h->f32.hd_data->d_q_qd_u, 3 * n, h->f32.d_robotModel, gravity, reps);
     GRID_TRY(hipGetLastError());
     GRID_TRY(hipDeviceSynchronize());
     clock_gettime(CLOCK_MONOTONIC, &end);
-    GRID_TRY(hipMemcpy(h_df_du, h->hd_data->d_df_du, (size_t)2 * n * n * sizeof(float), hipMemcpyDeviceToHost));
+    GRID_TRY(hipMemcpy(h_df_du, h->f32.hd_data->d_df_du, (size_t)2 * n * n * sizeof(float), hipMemcpyDeviceToHost));
     if (us_per_call) *us_per_call = time_delta_us_timespec(start, end) / (double)(reps > 0 ? reps : 1);
     return 0;
 }

@@ -140,14 +140,15 @@ def gen_lane_mask_test(self, ids, var_name="lane"):
     return "((0x%xull >> %s) & 1ull)" % (mask, var_name)
 
 
-def gen_kernel_prologue(self, lds_per_solve_const):
+def gen_kernel_prologue(self, lds_per_solve_const, max_groups_const="GRID_MAX_SOLVES_PER_BLOCK"):
     """Lane-group decomposition shared by every kernel.  Threads beyond the last whole lane group (or beyond
-    GRID_MAX_SOLVES_PER_BLOCK groups, which is what the *_DYNAMIC_SHARED_MEM_COUNT constants are sized for) retire."""
+    max_groups_const groups, which is what the kernel's *_DYNAMIC_SHARED_MEM_COUNT constant is sized for) retire, so a launch
+    with more threads than the kernel's suggested block size stays inside the LDS the host wrappers allocate."""
     self.gen_add_code_lines([
         "const int tid = threadIdx.x + threadIdx.y*blockDim.x;",
         "const int lane_id = tid & (GRID_LANES_PER_SOLVE-1); // lane j of a solve's lane group owns joint j",
         "const int grp = tid / GRID_LANES_PER_SOLVE;",
-        "int gpb = (blockDim.x*blockDim.y) / GRID_LANES_PER_SOLVE; if (gpb > GRID_MAX_SOLVES_PER_BLOCK) {gpb = GRID_MAX_SOLVES_PER_BLOCK;}",
+        "int gpb = (blockDim.x*blockDim.y) / GRID_LANES_PER_SOLVE; if (gpb > " + max_groups_const + ") {gpb = " + max_groups_const + ";}",
         "if (grp >= gpb) {return;}",
         "T *s_mem = reinterpret_cast<T *>(grid_smem_raw) + grp*" + lds_per_solve_const + ";",
         "// output staging lives behind this block's slices so that the records of a wave's lane groups are contiguous",
@@ -238,7 +239,7 @@ def gen_kernel_save_result(self, store_to_name, stride, amount, use_thread_group
     self.gen_add_code_line("// save down to global: wave-cooperative, coalesced")
     self.gen_add_code_line("{", True)
     self.gen_add_code_lines(["const int gw0 = grp & ~(GRID_SOLVES_PER_WAVE-1); // first lane group of this wave",
-                             "int nv = NUM_TIMESTEPS_OUT - (k - grp + gw0); { const int ng = gpb - gw0; nv = nv < ng ? nv : ng; nv = nv < GRID_SOLVES_PER_WAVE ? nv : GRID_SOLVES_PER_WAVE; }",
+                             "int nv = NUM_TIMESTEPS_OUT - (k - grp + gw0); { const int ng = gpb - gw0; nv = nv < ng ? nv : ng; nv = nv < GRID_SOLVES_PER_WAVE ? nv : GRID_SOLVES_PER_WAVE; nv = nv > 0 ? nv : 0; } // (a wave whose lane groups are all past the end of the batch writes nothing)",
                              "const int total = nv*" + str(amount) + "; // elements this wave writes",
                              "const T *src = " + load_from_name + " - (grp - gw0)*" + str(amount) + ";",
                              "T *dst = &d_" + store_to_name + "[static_cast<size_t>(k - grp + gw0)*" + str(amount) + "];",

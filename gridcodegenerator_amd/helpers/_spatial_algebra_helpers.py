@@ -157,18 +157,14 @@ def gen_spatial_algebra_helpers(self):
     Link inertias are rigid-body inertias (10 parameters: Ibar symmetric 3x3, h = m*c, m), so
     I*[w;v] = [Ibar w + h x v ; m v - h x w] costs 24 FMAs with 10 constants instead of a dense 36/36;
     a general symmetric 6x6 (e.g. a caller-supplied composite inertia) falls back to the dense form."""
-    import os
     lib = _SPATIAL_LIBRARY
-    if os.environ.get("GRID_PIN_VOLATILE", "1") == "0":  # experiment: pins as plain (movable) asm
-        lib = lib.replace('__device__ __forceinline__ void grid_pin(T &x) { asm("" : "+v"(x)); }', '__device__ __forceinline__ void grid_pin(T &x) { asm("" : "+v"(x)); }')
-        lib = lib.replace('for (int r = 0; r < 6; r++) { asm("" : "+v"(v[r])); }', 'for (int r = 0; r < 6; r++) { asm("" : "+v"(v[r])); }')
-    if os.environ.get("GRID_NO_PINS", "0") == "1":  # experiment: no pins at all
+    if self.tuning["no_pins"]:  # experiment: no pins at all
         lib = lib.replace('__device__ __forceinline__ void grid_pin(T &x) { asm("" : "+v"(x)); }', '__device__ __forceinline__ void grid_pin(T &x) { (void)x; }')
         lib = lib.replace('for (int r = 0; r < 6; r++) { asm("" : "+v"(v[r])); }', 'for (int r = 0; r < 6; r++) { (void)v[r]; }')
-    if os.environ.get("GRID_NO_WAVE_BARRIER", "0") == "1":  # experiment: fences only
+    if self.tuning["no_wave_barrier"]:  # experiment: fences only
         lib = lib.replace("    __builtin_amdgcn_wave_barrier();\n", "")
     store4 = "__builtin_memcpy(dst, v, 4*sizeof(T));"
-    if os.environ.get("GRID_NT_STORE", "1") == "1":  # streaming (non-temporal) output stores: the record is never re-read by the kernel (+2 % on the 7-DoF arm)
+    if self.tuning["nt_store"]:  # streaming (non-temporal) output stores: the record is never re-read by the kernel (+2 % on the 7-DoF arm)
         store4 = ("\n#if defined(__HIP_DEVICE_COMPILE__)\n    typedef T vec4_t __attribute__((ext_vector_type(4), aligned(4))); vec4_t x = {v[0], v[1], v[2], v[3]}; "
                   "__builtin_nontemporal_store(x, reinterpret_cast<vec4_t *>(dst));\n#else\n    __builtin_memcpy(dst, v, 4*sizeof(T));\n#endif\n")
     for line in lib.replace("@@STORE4@@", store4).strip("\n").split("\n"):

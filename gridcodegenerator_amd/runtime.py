@@ -34,27 +34,28 @@ def library_path(robot_name, build_dir=None):
     return os.path.join(build_dir or BUILD_DIR, robot_name, "libgrid_%s.so" % robot_name)
 
 
-def generate_header(robot, out_dir, namespace="grid", cols_per_lane=None):
+def generate_header(robot, out_dir, namespace="grid", cols_per_lane=None, tuning=None):
     """Runs GRiDCodeGenerator(robot).gen_all_code() with out_dir as the working directory (the generator writes
     <namespace>.cuh into the cwd, like the reference does)."""
     os.makedirs(out_dir, exist_ok=True)
     cwd = os.getcwd()
     os.chdir(out_dir)
     try:
-        GRiDCodeGenerator(robot, FILE_NAMESPACE=namespace, COLS_PER_LANE=cols_per_lane).gen_all_code()
+        GRiDCodeGenerator(robot, FILE_NAMESPACE=namespace, COLS_PER_LANE=cols_per_lane, tuning=tuning).gen_all_code()
     finally:
         os.chdir(cwd)
     return os.path.join(out_dir, namespace + ".cuh")
 
 
-def build_library(robot, build_dir=None, force=False, extra_flags=(), verbose=False, cols_per_lane=None):
-    """robot: a fixture name, a RobotModel, or any URDFParser-style robot object.  Returns the .so path."""
+def build_library(robot, build_dir=None, force=False, extra_flags=(), verbose=False, cols_per_lane=None, tuning=None):
+    """robot: a fixture name, a RobotModel, or any URDFParser-style robot object.  Returns the .so path.
+    tuning: generation-time knobs (GRiDCodeGenerator.TUNING_DEFAULTS); nothing is read from the environment."""
     if isinstance(robot, str):
         robot = RobotModel.from_fixture(robot)
     name = robot.name
     out_dir = os.path.join(build_dir or BUILD_DIR, name)
     so = library_path(name, build_dir)
-    header = generate_header(robot, out_dir, cols_per_lane=cols_per_lane)
+    header = generate_header(robot, out_dir, cols_per_lane=cols_per_lane, tuning=tuning)
     stamp = so + ".stamp"
     srcs_mtime = max(os.path.getmtime(p) for p in (header, CAPI_SRC, os.path.join(INCLUDE_DIR, "grid_capi.h")))
     sig = open(header).read() + open(CAPI_SRC).read() + " ".join(HIPCC_FLAGS + list(extra_flags))
@@ -104,6 +105,8 @@ class GridLibrary:
         self.path = path
         self.lib = ctypes.CDLL(path)
         L = self.lib
+        if not hasattr(L, "grid_forward_dynamics_gradient_multi_host"):
+            raise GridError("%s was built from an older grid_capi.hip - rebuild it (gridcodegenerator_amd.runtime.build_library)" % path)
         L.grid_robot_name.restype = ctypes.c_char_p
         L.grid_last_error.restype = ctypes.c_char_p
         self.n = L.grid_num_joints()
@@ -111,6 +114,7 @@ class GridLibrary:
         self.lanes_per_solve = L.grid_lanes_per_solve()
         self.suggested_threads = L.grid_suggested_threads()
         self.lds_bytes_per_block = L.grid_lds_bytes_per_block()
+        self.has_second_order = bool(L.grid_has_second_order())
         self.handle = ctypes.c_void_p()
         self._check(L.grid_init(ctypes.c_int(device), ctypes.c_int(max_timesteps), ctypes.byref(self.handle)))
         self.max_timesteps = max_timesteps
@@ -127,14 +131,81 @@ class GridLibrary:
     def set_launch_dims(self, blocks=0, threads=0):
         self._check(self.lib.grid_set_launch_dims(self.handle, ctypes.c_int(blocks), ctypes.c_int(threads)))
 
-    # ---- host-buffer entry point (H2D, launch, D2H, synchronous)
+    # ---- host-buffer entry points (H2D, launch, D2H, synchronous): NumPy arrays in, NumPy arrays out
+    def _host_in(self, a, cols, what, dtype=np.float32):
+        x = np.ascontiguousarray(a, dtype=dtype)
+        if x.ndim != 2 or x.shape[1] not in (cols if isinstance(cols, tuple) else (cols,)):
+            raise ValueError("%s must have shape (N, %s)" % (what, cols))
+        return x
+
     def forward_dynamics_gradient_host(self, q_qd_u, gravity=9.81):
-        x = np.ascontiguousarray(q_qd_u, dtype=np.float32)
-        if x.ndim != 2 or x.shape[1] != 3 * self.n:
-            raise ValueError("q_qd_u must have shape (N, %d)" % (3 * self.n))
+        x = self._host_in(q_qd_u, 3 * self.n, "q_qd_u")
         N = x.shape[0]
         out = np.empty((N, 2 * self.n * self.n), dtype=np.float32)
         self._check(self.lib.grid_forward_dynamics_gradient_host(self.handle, _ptr(x), ctypes.c_int(N), ctypes.c_float(gravity), _ptr(out)))
+        return out
+
+    def forward_dynamics_gradient_host_f64(self, q_qd_u, gravity=9.81):
+        x = self._host_in(q_qd_u, 3 * self.n, "q_qd_u", np.float64)
+        N = x.shape[0]
+        out = np.empty((N, 2 * self.n * self.n), dtype=np.float64)
+        self._check(self.lib.grid_forward_dynamics_gradient_host_f64(self.handle, ctypes.c_void_p(x.ctypes.data), ctypes.c_int(N), ctypes.c_double(gravity),
+                                                                     ctypes.c_void_p(out.ctypes.data)))
+        return out
+
+    def forward_dynamics_gradient_qdd_minv_host(self, q_qd, qdd, Minv, gravity=9.81):
+        n = self.n
+        x = self._host_in(q_qd, (2 * n, 3 * n), "q_qd")
+        N = x.shape[0]
+        a, M = self._host_in(qdd, n, "qdd"), self._host_in(Minv, n * n, "Minv")
+        out = np.empty((N, 2 * n * n), dtype=np.float32)
+        self._check(self.lib.grid_forward_dynamics_gradient_qdd_minv_host(self.handle, _ptr(x), ctypes.c_int(x.shape[1]), _ptr(a), _ptr(M), ctypes.c_int(N),
+                                                                          ctypes.c_float(gravity), _ptr(out)))
+        return out
+
+    def inverse_dynamics_host(self, q_qd, qdd=None, gravity=9.81):
+        n = self.n
+        x = self._host_in(q_qd, (2 * n, 3 * n), "q_qd")
+        a = None if qdd is None else self._host_in(qdd, n, "qdd")
+        out = np.empty((x.shape[0], n), dtype=np.float32)
+        self._check(self.lib.grid_inverse_dynamics_host(self.handle, _ptr(x), ctypes.c_int(x.shape[1]), _ptr(a), ctypes.c_int(x.shape[0]), ctypes.c_float(gravity), _ptr(out)))
+        return out
+
+    def inverse_dynamics_gradient_host(self, q_qd, qdd=None, gravity=9.81):
+        n = self.n
+        x = self._host_in(q_qd, (2 * n, 3 * n), "q_qd")
+        a = None if qdd is None else self._host_in(qdd, n, "qdd")
+        out = np.empty((x.shape[0], 2 * n * n), dtype=np.float32)
+        self._check(self.lib.grid_inverse_dynamics_gradient_host(self.handle, _ptr(x), ctypes.c_int(x.shape[1]), _ptr(a), ctypes.c_int(x.shape[0]), ctypes.c_float(gravity), _ptr(out)))
+        return out
+
+    def direct_minv_host(self, q):
+        n = self.n
+        x = self._host_in(q, (n, 2 * n, 3 * n), "q")
+        out = np.empty((x.shape[0], n * n), dtype=np.float32)
+        self._check(self.lib.grid_direct_minv_host(self.handle, _ptr(x), ctypes.c_int(x.shape[1]), ctypes.c_int(x.shape[0]), _ptr(out)))
+        return out
+
+    def forward_dynamics_host(self, q_qd_u, gravity=9.81, aba=False):
+        x = self._host_in(q_qd_u, 3 * self.n, "q_qd_u")
+        out = np.empty((x.shape[0], self.n), dtype=np.float32)
+        fn = self.lib.grid_aba_host if aba else self.lib.grid_forward_dynamics_host
+        self._check(fn(self.handle, _ptr(x), ctypes.c_int(x.shape[0]), ctypes.c_float(gravity), _ptr(out)))
+        return out
+
+    def idsva_so_host(self, q_qd_u, qdd=None, gravity=9.81):
+        n = self.n
+        x = self._host_in(q_qd_u, 3 * n, "q_qd_u")
+        a = None if qdd is None else self._host_in(qdd, n, "qdd")
+        out = np.empty((x.shape[0], 4 * n ** 3), dtype=np.float32)
+        self._check(self.lib.grid_idsva_so_host(self.handle, _ptr(x), _ptr(a), ctypes.c_int(x.shape[0]), ctypes.c_float(gravity), _ptr(out)))
+        return out
+
+    def fdsva_so_host(self, q_qd_u, gravity=9.81):
+        n = self.n
+        x = self._host_in(q_qd_u, 3 * n, "q_qd_u")
+        out = np.empty((x.shape[0], 4 * n ** 3), dtype=np.float32)
+        self._check(self.lib.grid_fdsva_so_host(self.handle, _ptr(x), ctypes.c_int(x.shape[0]), ctypes.c_float(gravity), _ptr(out)))
         return out
 
     def forward_dynamics_gradient_single_timing(self, q_qd_u_one, reps, gravity=9.81):
@@ -148,6 +219,23 @@ class GridLibrary:
     def forward_dynamics_gradient_device(self, d_q_qd_u, N, d_df_du, stride=None, gravity=9.81, stream=0):
         self._check(self.lib.grid_forward_dynamics_gradient_device(self.handle, _ptr(d_q_qd_u), ctypes.c_int(stride or 3 * self.n), ctypes.c_int(N),
                                                                    ctypes.c_float(gravity), _ptr(d_df_du), ctypes.c_void_p(stream)))
+
+    def prepare_forward_dynamics_gradient_device(self, d_q_qd_u, N, d_df_du, stride=None, gravity=9.81, stream=0):
+        """Returns a zero-argument callable that enqueues the same launch every time it is called: the ctypes argument objects are built
+        once, so a call costs one foreign-function call (an MPC loop re-launching on the same buffers; bench.py's step)."""
+        fn = self.lib.grid_forward_dynamics_gradient_device
+        args = (self.handle, _ptr(d_q_qd_u), ctypes.c_int(stride or 3 * self.n), ctypes.c_int(N), ctypes.c_float(gravity), _ptr(d_df_du), ctypes.c_void_p(stream))
+        check = self._check
+
+        def launch():
+            rc = fn(*args)
+            if rc:
+                check(rc)
+        return launch
+
+    def forward_dynamics_gradient_device_f64(self, d_q_qd_u, N, d_df_du, stride=None, gravity=9.81, stream=0):
+        self._check(self.lib.grid_forward_dynamics_gradient_device_f64(self.handle, _ptr(d_q_qd_u), ctypes.c_int(stride or 3 * self.n), ctypes.c_int(N),
+                                                                       ctypes.c_double(gravity), _ptr(d_df_du), ctypes.c_void_p(stream)))
 
     def forward_dynamics_gradient_qdd_minv_device(self, d_q_qd, d_qdd, d_Minv, N, d_df_du, stride=None, gravity=9.81, stream=0):
         self._check(self.lib.grid_forward_dynamics_gradient_qdd_minv_device(self.handle, _ptr(d_q_qd), ctypes.c_int(stride or 3 * self.n), _ptr(d_qdd), _ptr(d_Minv),
@@ -179,6 +267,35 @@ class GridLibrary:
     def inverse_dynamics_gradient_device(self, d_q_qd, d_qdd, N, d_dc_du, stride=None, gravity=9.81, stream=0):
         self._check(self.lib.grid_inverse_dynamics_gradient_device(self.handle, _ptr(d_q_qd), ctypes.c_int(stride or 3 * self.n), _ptr(d_qdd), ctypes.c_int(N),
                                                                    ctypes.c_float(gravity), _ptr(d_dc_du), ctypes.c_void_p(stream)))
+
+
+class MultiGpuGrid:
+    """One process driving G GPUs: G handles of one robot library, the batch cut into G contiguous ranges.
+    `devices` may repeat a device (several handles on one GPU: how the split is rehearsed on a one-GPU box)."""
+
+    def __init__(self, path, devices, max_timesteps=16384):
+        self.parts = [GridLibrary(path, device=d, max_timesteps=max_timesteps) for d in devices]
+        self.n = self.parts[0].n
+        self.lib = self.parts[0].lib
+
+    @staticmethod
+    def ranges(N, G):
+        """[k0, k1) of every device slot - the same arithmetic as csrc/grid_capi.hip: multi_range."""
+        per = (N + G - 1) // G
+        return [(min(g * per, N), min((g + 1) * per, N)) for g in range(G)]
+
+    def forward_dynamics_gradient_host(self, q_qd_u, gravity=9.81):
+        x = np.ascontiguousarray(q_qd_u, dtype=np.float32)
+        N = x.shape[0]
+        out = np.empty((N, 2 * self.n * self.n), dtype=np.float32)
+        hs = (ctypes.c_void_p * len(self.parts))(*[p.handle for p in self.parts])
+        rc = self.lib.grid_forward_dynamics_gradient_multi_host(hs, ctypes.c_int(len(self.parts)), _ptr(x), ctypes.c_int(N), ctypes.c_float(gravity), _ptr(out))
+        self.parts[0]._check(rc)
+        return out
+
+    def close(self):
+        for p in self.parts:
+            p.close()
 
 
 def load(robot_name, device=0, max_timesteps=16384, build_dir=None):

@@ -31,9 +31,26 @@ static void run(const std::vector<double> &in, int N, const std::string &prefix)
     const int gpb_so = IDSVA_SO_SUGGESTED_THREADS / GRID_LANES_PER_SOLVE;
     idsva_so_host<T, true>(hd_data, d_robotModel, g, N, dim3((N + gpb_so - 1) / gpb_so, 1, 1), dim3(IDSVA_SO_SUGGESTED_THREADS, 1, 1), streams);
     dump(prefix + "_so.bin", hd_data->h_idsva_so, (size_t)N * 4 * n * n * n);
+    {   // the header's general SUGGESTED_THREADS launch dims must work for every kernel (the reference's hosts accept any thread_dimms):
+        // lane groups beyond the kernel's own cap retire and the wrapper sizes the LDS for the capped count
+        std::vector<T> first(hd_data->h_idsva_so, hd_data->h_idsva_so + (size_t)N * 4 * n * n * n);
+        for (size_t i = 0; i < first.size(); i++) hd_data->h_idsva_so[i] = static_cast<T>(-1);
+        idsva_so_host<T, true>(hd_data, d_robotModel, g, N, blocks, threads, streams);
+        size_t bad = 0;
+        for (size_t i = 0; i < first.size(); i++) bad += (first[i] != hd_data->h_idsva_so[i]);
+        printf("idsva_so with SUGGESTED_THREADS: mismatches = %zu\n", bad);
+    }
     const int gpb_fd = FDSVA_SO_SUGGESTED_THREADS / GRID_LANES_PER_SOLVE;
     fdsva_so<T>(hd_data, d_robotModel, g, N, dim3((N + gpb_fd - 1) / gpb_fd, 1, 1), dim3(FDSVA_SO_SUGGESTED_THREADS, 1, 1), streams);
     dump(prefix + "_df2.bin", hd_data->h_df2, (size_t)N * 4 * n * n * n);
+    {
+        std::vector<T> first(hd_data->h_df2, hd_data->h_df2 + (size_t)N * 4 * n * n * n);
+        for (size_t i = 0; i < first.size(); i++) hd_data->h_df2[i] = static_cast<T>(-1);
+        fdsva_so<T>(hd_data, d_robotModel, g, N, blocks, threads, streams);
+        size_t bad = 0;
+        for (size_t i = 0; i < first.size(); i++) bad += (first[i] != hd_data->h_df2[i]);
+        printf("fdsva_so with SUGGESTED_THREADS: mismatches = %zu\n", bad);
+    }
     close_grid<T>(streams, d_robotModel, hd_data);
 }
 

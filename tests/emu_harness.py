@@ -12,23 +12,14 @@ EMU_INC = os.path.join(HERE, "emu")
 _CACHE = {}
 
 
-def emu_library(robot, max_timesteps=64, cols_per_lane=None, env=None):
-    """env: generation-time tuning knobs (GRID_* environment variables) for this build only."""
+def emu_library(robot, max_timesteps=64, cols_per_lane=None, tuning=None):
+    """tuning: generation-time knobs (GRiDCodeGenerator(..., tuning=...)) for this build only."""
     if isinstance(robot, str):
         robot = RobotModel.from_fixture(robot)
-    key = robot.name + ("" if cols_per_lane is None else "_c%d" % cols_per_lane) + "".join("_%s%s" % (k[5:].lower(), v) for k, v in sorted((env or {}).items()))
+    key = robot.name + ("" if cols_per_lane is None else "_c%d" % cols_per_lane) + "".join("_%s%s" % (k, v) for k, v in sorted((tuning or {}).items()))
     if key not in _CACHE:
         out_dir = os.path.join(tempfile.gettempdir(), "grid_emu_build", key)
-        saved = {k: os.environ.get(k) for k in (env or {})}
-        os.environ.update(env or {})
-        try:
-            generate_header(robot, out_dir, cols_per_lane=cols_per_lane)
-        finally:
-            for k, v in saved.items():
-                if v is None:
-                    os.environ.pop(k, None)
-                else:
-                    os.environ[k] = v
+        generate_header(robot, out_dir, cols_per_lane=cols_per_lane, tuning=tuning)
         so = os.path.join(out_dir, "libgrid_emu_%s.so" % key)
         cmd = ["g++", "-std=c++20", "-O0", "-g0", "-x", "c++", "-shared", "-fPIC", "-pthread", "-I" + EMU_INC, "-I" + out_dir, "-I" + INCLUDE_DIR,
                '-DGRID_ROBOT_NAME="%s"' % robot.name, "-Wno-unused-value", CAPI_SRC, "-o", so]

@@ -61,17 +61,17 @@ def test_emulated_one_column_per_lane_variant(name, golden):
     assert per_solve_err(dc, np.stack([g["dc_du"][k].T.reshape(-1) for k in range(N)])) <= TOL
 
 
-@pytest.mark.parametrize("name,env", [("iiwa14", {"GRID_GRADIENT_WALK": "lds"}), ("hyq", {"GRID_GRADIENT_WALK": "lds"}), ("atlas", {"GRID_GRADIENT_WALK": "lds"}),
-                                      ("iiwa14", {"GRID_REUSE_RNEA": "1"}), ("iiwa14", {"GRID_FUSE_FD": "0"}),
-                                      ("iiwa14", {"GRID_GRADIENT_WALK": "registers"}), ("iiwa14", {"GRID_TIP_CHAIN": "lds"}), ("arm6", {"GRID_GRADIENT_WALK": "registers"}),
-                                      ("iiwa14", {"GRID_GRADIENT_WALK": "branch"}), ("hyq", {"GRID_GRADIENT_WALK": "branch"}), ("chain12", {"GRID_GRADIENT_WALK": "branch"}),
-                                      ("atlas", {"GRID_GRADIENT_WALK": "registers"})])
-def test_emulated_generation_variants(name, env, golden):
+@pytest.mark.parametrize("name,tuning", [("iiwa14", {"gradient_walk": "lds"}), ("hyq", {"gradient_walk": "lds"}), ("atlas", {"gradient_walk": "lds"}),
+                                      ("iiwa14", {"reuse_rnea": True}), ("iiwa14", {"fuse_fd": False}),
+                                      ("iiwa14", {"gradient_walk": "registers"}), ("iiwa14", {"tip_chain": "lds"}), ("arm6", {"gradient_walk": "registers"}),
+                                      ("iiwa14", {"gradient_walk": "branch"}), ("hyq", {"gradient_walk": "branch"}), ("chain12", {"gradient_walk": "branch"}),
+                                      ("atlas", {"gradient_walk": "registers"})])
+def test_emulated_generation_variants(name, tuning, golden):
     """The non-default generated forms stay correct: LDS-assisted forward accumulation of the derivative walk (what deep trees get),
     RNEA re-use, unfused forward dynamics; the branch-frame path (default for branched revolute robots such as atlas) forced onto chains and
     forests (one branch / equal branches, 8- and 16-lane groups), and the column walk forced onto atlas."""
     g = golden(name)
-    lib = emu_library(name, max_timesteps=64, env=env)
+    lib = emu_library(name, max_timesteps=64, tuning=tuning)
     n = lib.n
     N = 5
     x = np.ascontiguousarray(np.hstack([g["q"], g["qd"], g["u"]]).astype(np.float32)[:N])
@@ -322,21 +322,16 @@ def test_emulated_random_trees_on_the_branch_frame_path(seed, n):
 def test_emulated_run_longer_than_a_dpp_row_is_split_into_branches():
     """A 20-joint chain does not fit one 16-lane DPP row: the branch-frame plan continues it as a child branch (a junction with one child) and
     the factors no longer fit the X(q) storage (they go behind the path axes).  auto mode leaves such a robot on the column walk (the
-    replicated factorisation of a dense 20-joint chain costs more than it saves); GRID_GRADIENT_WALK=branch forces the path."""
+    replicated factorisation of a dense 20-joint chain costs more than it saves); tuning={'gradient_walk': 'branch'} forces the path."""
     from gridcodegenerator_amd import GRiDCodeGenerator
     from gridcodegenerator_amd.fixtures.make_fixtures import chain12
     from oracle.rbd_oracle import Oracle
-    import os
 
     robot = RobotModel(chain12(20, 77, "chain20"))
     assert not GRiDCodeGenerator(robot).branch_frame
-    os.environ["GRID_GRADIENT_WALK"] = "branch"
-    try:
-        plan = GRiDCodeGenerator(robot).branch_plan
-    finally:
-        del os.environ["GRID_GRADIENT_WALK"]
+    plan = GRiDCodeGenerator(robot, tuning={"gradient_walk": "branch"}).branch_plan
     assert [len(b) for b in plan["branches"]] == [16, 4] and plan["level"] == [0, 1] and plan["place"]["U"][0] == "sp" and plan["factor_work"] == 1330
-    lib = emu_library(robot, max_timesteps=8, env={"GRID_GRADIENT_WALK": "branch"})
+    lib = emu_library(robot, max_timesteps=8, tuning={"gradient_walk": "branch"})
     n, N = 20, 3
     rng = np.random.default_rng(0)
     x = np.hstack([rng.uniform(-np.pi, np.pi, (N, n)), rng.uniform(-2, 2, (N, n)), rng.uniform(-10, 10, (N, n))]).astype(np.float32)

@@ -64,3 +64,24 @@ def test_fdsva_so_oracle_matches_finite_differences_of_the_first_order_oracle(na
         ref[1][:, :, k] = d[:, n:]
     for t in range(4):
         assert np.abs(got[t] - ref[t]).max() <= 2e-6 * max(np.abs(ref[t]).max(), 1.0), t
+
+
+def test_emulated_second_order_layout_from_first_order_kernels():
+    """CPU counterpart of tests/test_gpu_parity.py::test_second_order_tensor_layout_from_gpu_outputs_only: the generated second-order kernels'
+    [i][j][k] layout against central differences of the generated first-order kernels (pinned by the reference's goldens), in the emulation."""
+    import numpy as np
+
+    from emu_harness import emu_library
+    from so_layout_check import check_second_order_layout
+
+    lib = emu_library("iiwa14", max_timesteps=8)
+    lib.set_launch_dims(0, 64)
+
+    class Dev:
+        stream = 0
+        arr = staticmethod(lambda a: np.ascontiguousarray(a, dtype=np.float32))
+        full = staticmethod(lambda shape, v: np.full(shape, v, dtype=np.float32))
+        host = staticmethod(lambda a: a)
+
+    report = check_second_order_layout(lib, Dev, B=2)
+    assert max(report.values()) < 5e-2

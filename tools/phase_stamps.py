@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Reads the per-wave cycle stamps a GRID_DEBUG_STOP=20 build of the tip-frame kernel leaves in the first outputs of every solve.
+"""Reads the per-wave cycle stamps a tuning debug_stop=20 build (tools/build_variant.py iiwa14 stamps debug_stop=20 allow_wrong_results=1) of the tip-frame kernel leaves in the first outputs of every solve.
 usage: python tools/phase_stamps.py <build-dir> [batch] [robot]   (robot other than iiwa14: the branch-frame kernel's 8 stamps)"""
 import sys
 sys.path.insert(0, ".")
