@@ -15,9 +15,10 @@ value = solves processed by all ranks / max-over-ranks wall time of the K steps.
 Protocol of the timed region: `--warmup` untimed steps, barrier + synchronize, EXACTLY `--steps` launches bracketed by one HIP event
 pair on the launch stream, synchronize, barrier.  Before the warm-up steps a DISCLOSED, untimed clock warm ("clock_warm_ms") keeps the
 GPU busy so that a short run is not timed on a clock still ramping up from idle.  A second, diagnostic pass of K launches with one
-event per launch gives the per-launch distribution ("launch_us_median"); it is not part of `value`.
+event every 4 launches gives the per-launch distribution ("launch_us_median"); it is not part of `value`.
 """
 import argparse
+import gc
 import json
 import os
 import sys
@@ -245,11 +246,19 @@ def main():
                     step()
                 warm_launches += 64
                 torch.cuda.synchronize(dev)
+        # the W warm-up steps run through the SAME code path as the timed region (events recorded on the launch stream, synchronize):
+        # first-use costs of the event machinery must not land in a 20-step timed region
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record(stream)
         for _ in range(warmup):
             step()
+        ev1.record(stream)
+        torch.cuda.synchronize(dev)
+        ev0.elapsed_time(ev1)
         barrier()
         # ---- timed region: exactly K steps; ONE HIP event pair on the launch stream brackets it
-        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        gc.collect()
+        gc.disable()
         t0 = time.perf_counter()
         ev0.record(stream)
         for _ in range(steps):
@@ -257,18 +266,23 @@ def main():
         ev1.record(stream)
         torch.cuda.synchronize(dev)                 # this rank's K steps are complete ...
         elapsed = time.perf_counter() - t0           # ... so its clock stops here; the closing barrier below is not part of the workload
+        gc.enable()
         barrier()
         gpu_ms = ev0.elapsed_time(ev1)
         if distributed:
             elapsed = reduce_max(elapsed, dist, red_dev)  # job time = slowest rank (all ranks started together behind the opening barrier)
-        # ---- diagnostic pass (not part of `value`): one event per launch -> per-launch distribution
-        evs = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+        # ---- diagnostic pass (not part of `value`): an event every CHUNK launches -> distribution of the per-launch time.  (An event after
+        # every single launch puts a marker packet between the kernels that costs ~3 us, more than a third of the kernel itself.)
+        CHUNK = 4
+        nch = max(1, steps // CHUNK)
+        evs = [torch.cuda.Event(enable_timing=True) for _ in range(nch + 1)]
         evs[0].record(stream)
-        for i in range(steps):
-            step()
+        for i in range(nch):
+            for _ in range(CHUNK):
+                step()
             evs[i + 1].record(stream)
         torch.cuda.synchronize(dev)
-        per = np.array([evs[i].elapsed_time(evs[i + 1]) for i in range(steps)]) * 1e3  # us
+        per = np.array([evs[i].elapsed_time(evs[i + 1]) for i in range(nch)]) * 1e3 / CHUNK  # us per launch, chunk means
         barrier()
         total = (B if scaling == "strong" else world * B) * steps
         return {"x": x, "d_out": d_out, "N": N, "elapsed": elapsed, "gpu_ms": gpu_ms, "per_launch_us": per, "solves": total,
@@ -320,7 +334,7 @@ def main():
                          "traffic": traffic, "traffic_source": (PMC_FILE + " (rocprofv3 --pmc passes of this kernel build, not measured in this run)") if traffic else None,
                          "kernel": "forward_dynamics_gradient_kernel<float>", "launch_us": 1e3 * launch_ms,
                          "launch_us_median": float(np.median(per)), "launch_us_min": float(per.min()), "launch_us_max": float(per.max()),
-                         "launch_us_note": "launch_us = event pair around the K timed launches / K; median/min/max = diagnostic pass with one event per launch (event markers add ~1 us between launches)",
+                         "launch_us_note": "launch_us = event pair around the K timed launches / K; median/min/max = separate diagnostic pass, one event every 4 launches (span / 4; a marker after every launch costs ~3 us)",
                          "algorithmic_bytes_per_launch": bytes_per_solve * N,
                          "note": "the path is fp32-VALU bound (AI ~110 flop/B): see valu_issue_frac"},
             # solves/s x the REFERENCE's 53 kflop per solve / peak fp32: a reference-equivalent rate, NOT the utilisation of this kernel

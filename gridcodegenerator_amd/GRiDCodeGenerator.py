@@ -27,6 +27,9 @@ TUNING_DEFAULTS = {
     "dpp_asm": True,            # lane-group scans as single v_fmac_f32_dpp instructions (inline asm) instead of builtin DPP move + FMA
     "tip_chain": "select",      # select | lds: how the tip-frame chain hands (R, p) to the owning lane
     "nt_store": True,           # non-temporal output stores
+    "composite_scan": "f32",    # f32 | f64: precision of the suffix sums of the link inertias (tip/branch-frame paths); f64 = exact sums, rounded once
+    "base_origin": "auto",      # auto | off | <joint position>: tip-frame path - the joint-space inertia entries of the base half of a chain are
+                                # evaluated about the origin of this joint instead of the tip (fp32 accuracy); auto = L // 2 for L >= 5
 }
 TUNING_ABLATION = {
     "debug_stop": 0,            # truncate the kernel after a phase / cycle stamps (tools/prof_ablation.sh, tools/phase_stamps.py)
@@ -142,6 +145,16 @@ class GRiDCodeGenerator:
         equal = chains and len(set(L_ for _, L_ in segs)) == 1 and all([m_.S_index[st + i] for i in range(L_)] == [m_.S_index[i] for i in range(L_)] for st, L_ in segs)
         tip_ok = bool(chains and equal and all(s_ < 3 for s_ in m_.S_index) and COLS_PER_LANE == 2 and lanes <= 16)
         self.tip_L, self.tip_nseg = (segs[0][1], len(segs)) if tip_ok else (n, 1)
+        bo = self.tuning["base_origin"]
+        if bo == "auto":
+            self.tip_jB = self.tip_L // 2 if (tip_ok and self.tip_L >= 5) else None
+        elif bo in ("off", None, False):
+            self.tip_jB = None
+        else:
+            self.tip_jB = int(bo)
+            if not (tip_ok and 0 <= self.tip_jB < self.tip_L - 1):
+                raise ValueError("tuning['base_origin'] must be auto, off or a joint position 0 .. L-2 of a tip-frame robot")
+        self.tip_rec = 20 if self.tip_jB is not None else 16  # values per joint in the hand-off records of the tip-frame inner
         if mode == "tipframe" and not tip_ok:
             raise NotImplementedError("gradient_walk=tipframe needs a serial chain of revolute joints (or a forest of equal such chains) with at most 16 joints")
         self.tip_frame = tip_ok and mode in ("auto", "tipframe") and not DEBUG_MODE  # (DEBUG_MODE prints M^-1, which this path never forms)

@@ -209,7 +209,7 @@ def _probe(self, stage, *arrays):
         self.gen_add_code_line("for (int r = 0; r < %s; r++) { %s[r] = static_cast<T>(static_cast<float>(%s[r])); } // round_probe %s" % (ln, nm, nm, stage))
 
 
-def _chain_step(self, i, s_F=None, with_gravity=True):
+def _chain_step(self, i, s_F=None, with_gravity=True, base_family=False):
     """Frame-chain step of the joint at position i of every chain: hand (R, p) to the lane that owns that joint, then move the running
     frame to the parent (or, for the root, read off the world's gravity direction).  The hand-off is a register select on every lane
     (s_F None) or one LDS record per joint written by lane 0 and read back by its owner after the chain (single chains only)."""
@@ -221,6 +221,8 @@ def _chain_step(self, i, s_F=None, with_gravity=True):
     C = lambda x: "static_cast<T>(" + repr(float(x)) + ")"
     J = str(i) if nseg == 1 else "(base + %d)" % i
     self.gen_add_code_line("{ // tip-frame chain, position %d: the lane of that joint keeps (R, p) of its frame; then on to the frame of its parent" % i, True)
+    if base_family and self.tip_jB is not None and i == self.tip_jB:
+        self.gen_add_code_line("pB[0] = pc[0]; pB[1] = pc[1]; pB[2] = pc[2]; // origin of the base family: the frame origin of the joint at position %d" % i)
     if s_F is None:
         self.gen_add_code_line("#pragma unroll")
         self.gen_add_code_line("for (int r = 0; r < 9; r++) { myR[r] = (pos == %d) ? Rc[r] : myR[r]; }" % i)
@@ -263,13 +265,15 @@ def _emit_chain_decls(self):
     self.gen_add_code_line("T Rc[9] = {static_cast<T>(1), static_cast<T>(0), static_cast<T>(0), static_cast<T>(0), static_cast<T>(1), static_cast<T>(0), static_cast<T>(0), static_cast<T>(0), static_cast<T>(1)};")
     self.gen_add_code_line("T pc[3] = {static_cast<T>(0), static_cast<T>(0), static_cast<T>(0)};")
     self.gen_add_code_line("T myR[9], myp[3], gvec[3];")
+    if self.tip_jB is not None:
+        self.gen_add_code_line("T pB[3] = {static_cast<T>(0), static_cast<T>(0), static_cast<T>(0)}; // second reference point (see _emit_base_family)")
     self.gen_add_code_line("#pragma unroll")
     self.gen_add_code_line("for (int r = 0; r < 9; r++) { myR[r] = Rc[r]; }")
     self.gen_add_code_line("#pragma unroll")
     self.gen_add_code_line("for (int r = 0; r < 3; r++) { myp[r] = pc[r]; }")
 
 
-def _emit_link_setup(self, kinematics=True):
+def _emit_link_setup(self, kinematics=True, base_family=False):
     """Per lane: joint axis S and link inertia in F coordinates; with kinematics also the velocity prefix sum and Pd = S-dot."""
     m = self.model
     n = m.n
@@ -290,8 +294,10 @@ def _emit_link_setup(self, kinematics=True):
         self.gen_add_code_line("  for (int r = 0; r < 3; r++) { S[r] = (ax == 0) ? myR[3*r] : ((ax == 1) ? myR[3*r+1] : myR[3*r+2]); } }")
     self.gen_add_code_line("S[3] = myp[1]*S[2] - myp[2]*S[1]; S[4] = myp[2]*S[0] - myp[0]*S[2]; S[5] = myp[0]*S[1] - myp[1]*S[0];")
     self.gen_add_code_line("T I[10]; // this link's inertia about the origin of F")
+    if base_family and self.tip_jB is not None:
+        self.gen_add_code_line("T IB[10], SB[3]; // ... and about pB, and the linear part of S about pB (base family, see _emit_base_family)")
     self.gen_add_code_line("{", True)
-    self.gen_add_code_line("T d[3], RI[9];")
+    self.gen_add_code_line("T d[3], RI[9], rot[6];")
     self.gen_add_code_line("#pragma unroll")
     self.gen_add_code_line("for (int r = 0; r < 3; r++) {", True)
     self.gen_add_code_line("d[r] = myp[r] + myR[3*r]*Lc[6] + myR[3*r+1]*Lc[7] + myR[3*r+2]*Lc[8]; // centre of mass")
@@ -299,15 +305,26 @@ def _emit_link_setup(self, kinematics=True):
     self.gen_add_code_line("RI[3*r+1] = myR[3*r]*Lc[1] + myR[3*r+1]*Lc[3] + myR[3*r+2]*Lc[4];")
     self.gen_add_code_line("RI[3*r+2] = myR[3*r]*Lc[2] + myR[3*r+1]*Lc[4] + myR[3*r+2]*Lc[5];")
     self.gen_add_end_control_flow()
-    self.gen_add_code_line("const T md0 = Lc[9]*d[0], md1 = Lc[9]*d[1], md2 = Lc[9]*d[2];")
-    for k, (r_, c_) in enumerate(((0, 0), (0, 1), (0, 2), (1, 1), (1, 2), (2, 2))):
-        rot = "RI[%d]*myR[%d] + RI[%d]*myR[%d] + RI[%d]*myR[%d]" % (3 * r_, 3 * c_, 3 * r_ + 1, 3 * c_ + 1, 3 * r_ + 2, 3 * c_ + 2)
-        if r_ == c_:
-            o1, o2 = [x for x in range(3) if x != r_]
-            self.gen_add_code_line("I[%d] = %s + md%d*d[%d] + md%d*d[%d];" % (k, rot, o1, o1, o2, o2))
-        else:
-            self.gen_add_code_line("I[%d] = %s - md%d*d[%d];" % (k, rot, r_, c_))
-    self.gen_add_code_line("I[6] = md0; I[7] = md1; I[8] = md2; I[9] = Lc[9];")
+    pairs = ((0, 0), (0, 1), (0, 2), (1, 1), (1, 2), (2, 2))
+    for k, (r_, c_) in enumerate(pairs):
+        self.gen_add_code_line("rot[%d] = RI[%d]*myR[%d] + RI[%d]*myR[%d] + RI[%d]*myR[%d]; // (R Ic R^T)[%d][%d]" % (k, 3 * r_, 3 * c_, 3 * r_ + 1, 3 * c_ + 1, 3 * r_ + 2, 3 * c_ + 2, r_, c_))
+
+    def parallel_axis(dst, dv):
+        self.gen_add_code_line("{ const T md0 = Lc[9]*%s[0], md1 = Lc[9]*%s[1], md2 = Lc[9]*%s[2];" % (dv, dv, dv))
+        for k, (r_, c_) in enumerate(pairs):
+            if r_ == c_:
+                o1, o2 = [x for x in range(3) if x != r_]
+                self.gen_add_code_line("  %s[%d] = rot[%d] + md%d*%s[%d] + md%d*%s[%d];" % (dst, k, k, o1, dv, o1, o2, dv, o2))
+            else:
+                self.gen_add_code_line("  %s[%d] = rot[%d] - md%d*%s[%d];" % (dst, k, k, r_, dv, c_))
+        self.gen_add_code_line("  %s[6] = md0; %s[7] = md1; %s[8] = md2; %s[9] = Lc[9]; }" % (dst, dst, dst, dst))
+
+    parallel_axis("I", "d")
+    if base_family and self.tip_jB is not None:
+        self.gen_add_code_line("T dB[3] = {d[0] - pB[0], d[1] - pB[1], d[2] - pB[2]}; // centre of mass relative to pB")
+        parallel_axis("IB", "dB")
+        self.gen_add_code_line("{ const T e0 = myp[0] - pB[0], e1 = myp[1] - pB[1], e2 = myp[2] - pB[2];")
+        self.gen_add_code_line("  SB[0] = e1*S[2] - e2*S[1]; SB[1] = e2*S[0] - e0*S[2]; SB[2] = e0*S[1] - e1*S[0]; }")
     self.gen_add_end_control_flow()
     if not kinematics:
         return
@@ -346,9 +363,54 @@ def _emit_bias(self, with_qdd):
     self.gen_add_code_line("#pragma unroll")
     self.gen_add_code_line("for (int r = 0; r < 6; r++) { BC[6 + r] = Iv[r]; }")
     self.gen_add_end_control_flow()
+    _emit_inertia_composite(self)
+    self.gen_add_code_line("grid_suffix_sum(BC, mkd); grid_suffix_sum(fC, mkd); // composites over the links j..n-1")
+
+
+def _emit_inertia_composite(self):
+    """IC = suffix sum of the link inertias I (about the origin of F).  The entries of the base links are ~m d^2 with d the distance to the tip
+    (25 kg m^2 for the 7-DoF arm) while the joint-space inertia they end up in can be 1e-2: the three rounding steps of an fp32 log-step scan
+    at that magnitude are the largest single contribution to the fp32 error of the path (tools/precision_probe.py).  composite_scan = f64
+    adds the nine inertia entries in double precision (exact for these magnitudes) and rounds once."""
     self.gen_add_code_line("#pragma unroll")
     self.gen_add_code_line("for (int r = 0; r < 10; r++) { IC[r] = I[r]; }")
-    self.gen_add_code_line("grid_suffix_sum(IC, mkd); grid_suffix_sum(BC, mkd); grid_suffix_sum(fC, mkd); // composites over the links j..n-1")
+    if self.tuning["composite_scan"] == "f64":
+        self.gen_add_code_line("{ // exact suffix sums of the 9 inertia entries (double accumulators), one rounding at the end; the mass stays in T")
+        self.gen_add_code_line("  double ICd[9], mkdd[GRID_SCAN_STEPS];")
+        self.gen_add_code_line("  #pragma unroll")
+        self.gen_add_code_line("  for (int r = 0; r < 9; r++) { ICd[r] = static_cast<double>(I[r]); }")
+        self.gen_add_code_line("  #pragma unroll")
+        self.gen_add_code_line("  for (int r = 0; r < GRID_SCAN_STEPS; r++) { mkdd[r] = static_cast<double>(mkd[r]); }")
+        self.gen_add_code_line("  grid_suffix_sum(ICd, mkdd);")
+        self.gen_add_code_line("  #pragma unroll")
+        self.gen_add_code_line("  for (int r = 0; r < 9; r++) { IC[r] = static_cast<T>(ICd[r]); }")
+        self.gen_add_code_line("  T mC[1] = {I[9]}; grid_suffix_sum(mC, mkd); IC[9] = mC[0]; }")
+    else:
+        self.gen_add_code_line("grid_suffix_sum(IC, mkd);")
+
+
+def _emit_base_family(self):
+    """Second reference point for the joint-space inertia (fp32 accuracy; the T = double instantiation runs the same code).
+    M[k][j] = S_k . (I^C_j S_j) is a moment about joint axis k.  About the tip - up to the whole arm's length away from the base joints - it is
+    a small difference of terms of size m d^2 (25 kg m^2 for the 7-DoF arm against entries of 1e-2 .. 1): ~1e-6 relative error per entry in fp32,
+    amplified up to 50x where two base axes are nearly parallel (shoulder + elbow lined up).  The columns j <= jB (the base half of the chain)
+    therefore take their entries from composites about pB, the frame origin of joint jB, where those terms are an order of magnitude smaller;
+    the columns of the wrist half keep the tip (their own neighbourhood).  Costs one more suffix scan of 9 values, one more I^C S product and 3
+    more values per hand-off record.  Leaves t1m (the I^C S this lane's column of M is built from) and `fam` (1: base family)."""
+    jB = self.tip_jB
+    self.gen_add_code_line("// base family: composites of the link inertias about pB for the columns of M owned by the joints at positions <= %d" % jB)
+    self.gen_add_code_line("const bool fam = (pos <= %d);" % jB)
+    self.gen_add_code_line("T t1m[6];")
+    self.gen_add_code_line("{", True)
+    self.gen_add_code_line("T ICB[10], x[6], y[6];")
+    self.gen_add_code_line("#pragma unroll")
+    self.gen_add_code_line("for (int r = 0; r < 10; r++) { ICB[r] = IB[r]; }")
+    self.gen_add_code_line("grid_suffix_sum(ICB, mkd);")
+    self.gen_add_code_line("x[0] = S[0]; x[1] = S[1]; x[2] = S[2]; x[3] = SB[0]; x[4] = SB[1]; x[5] = SB[2];")
+    self.gen_add_code_line("grid_rbi_mul(y, ICB, x);")
+    self.gen_add_code_line("#pragma unroll")
+    self.gen_add_code_line("for (int r = 0; r < 6; r++) { t1m[r] = fam ? y[r] : t1[r]; }")
+    self.gen_add_end_control_flow()
 
 
 def _own_rows(self, dst_fmt, val_fmt, zero="static_cast<T>(0)"):
@@ -495,8 +557,10 @@ def gen_forward_dynamics_gradient_inner_tip(self, use_thread_group=False, use_qd
     _emit_chain_decls(self)
     chain_lds = (not use_qdd_Minv_input) and self.tip_nseg == 1 and self.tuning["tip_chain"] == "lds"
     L = self.tip_L
+    bf = (not use_qdd_Minv_input) and self.tip_jB is not None
+    RS = self.tip_rec if not use_qdd_Minv_input else 16  # values per hand-off record
     for i in range(L - 1, -1, -1):
-        _chain_step(self, i, "s_G" if chain_lds else None)
+        _chain_step(self, i, "s_G" if chain_lds else None, base_family=bf)
     if chain_lds:
         self.gen_add_sync(use_thread_group)
         self.gen_add_code_line("if (lane < %d) { // this lane's own frame (lanes without a joint keep the identity; their link constants are zero)" % (n - 1), True)
@@ -523,7 +587,7 @@ def gen_forward_dynamics_gradient_inner_tip(self, use_thread_group=False, use_qd
         self.gen_add_code_line("grid_pin(myR[0]); grid_pin(myp[0]); grid_pin(gvec[0]);")
     TS(1)
     _probe(self, "chain", "myR:9", "myp:3", "gvec:3")
-    _emit_link_setup(self)
+    _emit_link_setup(self, base_family=bf)
     _probe(self, "link", "S:6", "I:10")
     _probe(self, "vel", "v:6", "Pd:6")
     _emit_bias(self, False)
@@ -536,18 +600,22 @@ def gen_forward_dynamics_gradient_inner_tip(self, use_thread_group=False, use_qd
     self.gen_add_code_line("grid_btmul(t4, BC, S);")
     _probe(self, "t1", "t1:6")
     _probe(self, "t24", "t2:6", "t4:3")
+    if bf:
+        _emit_base_family(self)
     self.gen_add_code_line("if (lane < %d) {" % n, True)
-    self.gen_add_code_line("T *rec = &s_G[16*lane];")
+    self.gen_add_code_line("T *rec = &s_G[%d*lane];" % RS)
     self.gen_add_code_line("#pragma unroll")
     self.gen_add_code_line("for (int r = 0; r < 6; r++) { rec[r] = S[r]; rec[6 + r] = t1[r]; }")
     self.gen_add_code_line("rec[12] = t4[0]; rec[13] = t4[1]; rec[14] = t4[2]; rec[15] = s_u[lane] - (grid_dot6(S, fC) + Lc[10]*qd);")
+    if bf:
+        self.gen_add_code_line("rec[16] = SB[0]; rec[17] = SB[1]; rec[18] = SB[2]; rec[19] = static_cast<T>(0); // linear part of S about pB")
     if "rhs" in tuple(self.tuning.get("round_probe", ())):
         self.gen_add_code_line("rec[15] = static_cast<T>(static_cast<float>(rec[15]));")
     self.gen_add_end_control_flow()
     self.gen_add_sync(use_thread_group)
     TS(2)
     if stop == 6:
-        self.gen_add_code_line("if (lane < %d) { s_df_du[lane] = s_G[16*lane + 15] + t2[0] + t2[1] + t2[2] + t2[3] + t2[4] + t2[5]; }" % n)
+        self.gen_add_code_line("if (lane < %d) { s_df_du[lane] = s_G[%d*lane + 15] + t2[0] + t2[1] + t2[2] + t2[3] + t2[4] + t2[5]; }" % (n, RS))
         self.gen_add_end_function()
         return
     self.gen_add_code_line("// pass 1 over the records: column `lane` of M (rows k <= lane), column `lane` of dc/dqd (complete: it does not depend on qdd),")
@@ -558,10 +626,14 @@ def gen_forward_dynamics_gradient_inner_tip(self, use_thread_group=False, use_qd
         self.gen_add_code_line("Mcol[%d] = static_cast<T>(0);" % k)
     self.gen_add_code_line("#pragma unroll")
     self.gen_add_code_line("for (int k = 0; k < %d; k++) {" % L, True)
-    self.gen_add_code_line("T g[16];")
+    self.gen_add_code_line("T g[%d];" % RS)
     self.gen_add_code_line("#pragma unroll")
-    self.gen_add_code_line("for (int r = 0; r < 16; r++) { g[r] = s_G[16*(base + k) + r]; }")
-    self.gen_add_code_line("const T mkj  = g[0]*t1[0] + g[1]*t1[1] + g[2]*t1[2] + g[3]*t1[3] + g[4]*t1[4] + g[5]*t1[5];")
+    self.gen_add_code_line("for (int r = 0; r < %d; r++) { g[r] = s_G[%d*(base + k) + r]; }" % (RS, RS))
+    if bf:
+        self.gen_add_code_line("const T l0 = fam ? g[16] : g[3], l1 = fam ? g[17] : g[4], l2 = fam ? g[18] : g[5]; // linear part of S_k about this column's reference point")
+        self.gen_add_code_line("const T mkj  = g[0]*t1m[0] + g[1]*t1m[1] + g[2]*t1m[2] + l0*t1m[3] + l1*t1m[4] + l2*t1m[5];")
+    else:
+        self.gen_add_code_line("const T mkj  = g[0]*t1[0] + g[1]*t1[1] + g[2]*t1[2] + g[3]*t1[3] + g[4]*t1[4] + g[5]*t1[5];")
     self.gen_add_code_line("const T up_d = g[0]*t2[0] + g[1]*t2[1] + g[2]*t2[2] + g[3]*t2[3] + g[4]*t2[4] + g[5]*t2[5];")
     self.gen_add_code_line("const T lo_d = static_cast<T>(2)*(g[6]*Pd[0] + g[7]*Pd[1] + g[8]*Pd[2] + g[9]*Pd[3] + g[10]*Pd[4] + g[11]*Pd[5]) + g[12]*S[0] + g[13]*S[1] + g[14]*S[2];")
     self.gen_add_code_line("dq[k] = g[12]*Pd[0] + g[13]*Pd[1] + g[14]*Pd[2];")
@@ -617,7 +689,7 @@ def gen_forward_dynamics_gradient_inner_tip(self, use_thread_group=False, use_qd
     self.gen_add_code_line("for (int k = 0; k < %d; k++) {" % L, True)
     self.gen_add_code_line("T g[12];")
     self.gen_add_code_line("#pragma unroll")
-    self.gen_add_code_line("for (int r = 0; r < 12; r++) { g[r] = s_G[16*(base + k) + r]; }")
+    self.gen_add_code_line("for (int r = 0; r < 12; r++) { g[r] = s_G[%d*(base + k) + r]; }" % RS)
     self.gen_add_code_line("const T up_q = g[0]*t3[0] + g[1]*t3[1] + g[2]*t3[2] + g[3]*t3[3] + g[4]*t3[4] + g[5]*t3[5];")
     self.gen_add_code_line("const T lo_q = g[6]*Pdd[0] + g[7]*Pdd[1] + g[8]*Pdd[2] + g[9]*Pdd[3] + g[10]*Pdd[4] + g[11]*Pdd[5] + dq[k];")
     self.gen_add_code_line("dq[k] = (k <= pos) ? up_q : lo_q;")
@@ -669,18 +741,23 @@ def _emit_force_only(self, with_qdd):
 
 
 def _emit_mass_matrix_factor(self, use_thread_group, rhs_expr=None):
-    """IC -> t1 = I^C S, record [S | t1 | . | rhs], M column by dots, hand-off, wave-uniform factorisation (leaves Uf*, rd*; rhs[] if asked)."""
+    """IC -> t1 = I^C S, record [S | rhs | . | S lin about pB], M column by dots, hand-off, wave-uniform factorisation (leaves Uf*, rd*; rhs[] if asked)."""
     n = self.model.n
     L = self.tip_L
     Lp = (L + 3) // 4 * 4
     ld = self.minv_ld
+    bf = self.tip_jB is not None
     self.gen_add_code_line("T t1[6]; grid_rbi_mul(t1, IC, S);")
+    if bf:
+        _emit_base_family(self)
     self.gen_add_code_line("if (lane < %d) {" % n, True)
     self.gen_add_code_line("T *rec = &s_G[16*lane];")
     self.gen_add_code_line("#pragma unroll")
     self.gen_add_code_line("for (int r = 0; r < 6; r++) { rec[r] = S[r]; }")
     if rhs_expr is not None:
         self.gen_add_code_line("rec[6] = %s;" % rhs_expr)
+    if bf:
+        self.gen_add_code_line("rec[8] = SB[0]; rec[9] = SB[1]; rec[10] = SB[2]; // linear part of S about pB")
     self.gen_add_end_control_flow()
     self.gen_add_sync(use_thread_group)
     self.gen_add_code_line("T Mcol[%d]%s;" % (Lp, (", rhs[%d]" % L) if rhs_expr is not None else ""))
@@ -688,10 +765,15 @@ def _emit_mass_matrix_factor(self, use_thread_group, rhs_expr=None):
         self.gen_add_code_line("Mcol[%d] = static_cast<T>(0);" % k)
     self.gen_add_code_line("#pragma unroll")
     self.gen_add_code_line("for (int k = 0; k < %d; k++) { // M[k][lane] = S_k . (I^C_lane S_lane), rows k <= lane of the lane's own chain" % L, True)
-    self.gen_add_code_line("T g[8];")
+    nr = 12 if bf else 8
+    self.gen_add_code_line("T g[%d];" % nr)
     self.gen_add_code_line("#pragma unroll")
-    self.gen_add_code_line("for (int r = 0; r < 8; r++) { g[r] = s_G[16*(base + k) + r]; }")
-    self.gen_add_code_line("Mcol[k] = g[0]*t1[0] + g[1]*t1[1] + g[2]*t1[2] + g[3]*t1[3] + g[4]*t1[4] + g[5]*t1[5];")
+    self.gen_add_code_line("for (int r = 0; r < %d; r++) { g[r] = s_G[16*(base + k) + r]; }" % nr)
+    if bf:
+        self.gen_add_code_line("const T l0 = fam ? g[8] : g[3], l1 = fam ? g[9] : g[4], l2 = fam ? g[10] : g[5]; // linear part of S_k about this column's reference point")
+        self.gen_add_code_line("Mcol[k] = g[0]*t1m[0] + g[1]*t1m[1] + g[2]*t1m[2] + l0*t1m[3] + l1*t1m[4] + l2*t1m[5];")
+    else:
+        self.gen_add_code_line("Mcol[k] = g[0]*t1[0] + g[1]*t1[1] + g[2]*t1[2] + g[3]*t1[3] + g[4]*t1[4] + g[5]*t1[5];")
     if rhs_expr is not None:
         self.gen_add_code_line("rhs[k] = g[6];")
     self.gen_add_end_control_flow()
@@ -705,7 +787,7 @@ def _emit_mass_matrix_factor(self, use_thread_group, rhs_expr=None):
     _emit_ldl_factor(self)
 
 
-def _tip_inner_header(self, name, doc, notes, params, sig, with_gravity=True):
+def _tip_inner_header(self, name, doc, notes, params, sig, with_gravity=True, base_family=False):
     self.gen_add_func_doc(doc, ["serial revolute chains: computed in the frame of the tip link (algorithms/_tip_frame_gradient.py)"] + notes,
                           params + ["d_robotModel is the pointer to the initialized model specific helpers on the GPU", "lane is the caller's lane index inside the solve's lane group"], None)
     self.gen_add_code_line("template <typename T>")
@@ -714,7 +796,7 @@ def _tip_inner_header(self, name, doc, notes, params, sig, with_gravity=True):
     _emit_link_constants_load(self)
     _emit_chain_decls(self)
     for i in range(self.tip_L - 1, -1, -1):
-        _chain_step(self, i, None, with_gravity)
+        _chain_step(self, i, None, with_gravity, base_family=base_family)
 
 
 def gen_inverse_dynamics_inner_tip(self, use_thread_group=False):
@@ -754,8 +836,8 @@ def gen_forward_dynamics_inner_tip(self, use_thread_group=False):
                       ["s_qdd is the output vector of joint accelerations in LDS", "s_qd is the vector of joint velocities in LDS", "s_u is the vector of joint input torques in LDS",
                        "s_X is this solve's compact X(q) storage", "s_G is LDS scratch for the per-joint hand-off records (16 values per joint)",
                        "s_M is LDS scratch for the joint-space inertia matrix (leading dimension GRID_MINV_LD)", "gravity is the gravity constant"],
-                      "T *s_qdd, const T *s_qd, const T *s_u, const T *s_X, T *s_G, T *s_M, const T gravity")
-    _emit_link_setup(self)
+                      "T *s_qdd, const T *s_qd, const T *s_u, const T *s_X, T *s_G, T *s_M, const T gravity", base_family=True)
+    _emit_link_setup(self, base_family=True)
     _emit_force_only(self, False)
     self.gen_add_code_line("T IC[10];")
     self.gen_add_code_line("#pragma unroll")
@@ -778,9 +860,9 @@ def gen_direct_minv_inner_tip(self, use_thread_group=False):
                       ["lane j writes row j (= column j); the caller must grid_wave_sync() before other lanes' entries are read"],
                       ["s_Minv is the n x n output in LDS (leading dimension GRID_MINV_LD); it also holds M itself on the way",
                        "s_X is this solve's compact X(q) storage", "s_G is LDS scratch for the per-joint hand-off records (16 values per joint)"],
-                      "T *s_Minv, const T *s_X, T *s_G", with_gravity=False)
+                      "T *s_Minv, const T *s_X, T *s_G", with_gravity=False, base_family=True)
     self.gen_add_code_line("T *s_M = s_Minv;")
-    _emit_link_setup(self, kinematics=False)
+    _emit_link_setup(self, kinematics=False, base_family=True)
     self.gen_add_code_line("T IC[10];")
     self.gen_add_code_line("#pragma unroll")
     self.gen_add_code_line("for (int r = 0; r < 10; r++) { IC[r] = I[r]; }")
