@@ -83,7 +83,7 @@ class GRiDCodeGenerator:
         gen_forward_dynamics_inner_function_call, gen_forward_dynamics_inner, gen_forward_dynamics_device, gen_forward_dynamics_kernel, \
         gen_forward_dynamics_host, gen_forward_dynamics, \
         gen_aba_inner_temp_mem_size, gen_aba_inner_function_call, gen_aba_inner, gen_aba_device, gen_aba_kernel, gen_aba_host, gen_aba, \
-        gen_idsva_so_available, gen_idsva_so_lds_layout, gen_idsva_so_inner_temp_mem_size, gen_idsva_so_inner_function_call, gen_idsva_so_inner, gen_idsva_so_device, gen_idsva_so_kernel, gen_idsva_so_host, gen_idsva_so, \
+        gen_idsva_so_available, gen_idsva_so_mode, gen_idsva_so_rec, gen_idsva_so_tree_tables, gen_idsva_so_lds_layout, gen_idsva_so_inner_temp_mem_size, gen_idsva_so_inner_function_call, gen_idsva_so_inner, gen_idsva_so_device, gen_idsva_so_kernel, gen_idsva_so_host, gen_idsva_so, \
         gen_fdsva_so_inner_temp_mem_size, gen_fdsva_so_stage_size, gen_fdsva_so_inner, gen_fdsva_so_device, gen_fdsva_so_kernel, gen_fdsva_so_host, gen_fdsva_so, \
         gen_inverse_dynamics_gradient_inner_temp_mem_size, gen_inverse_dynamics_gradient_kernel_max_temp_mem_size, \
         gen_inverse_dynamics_gradient_inner_function_call, gen_inverse_dynamics_gradient_inner, gen_dc_du_to_lds, gen_gradient_slots, gen_gradient_outputs_decl, \
@@ -259,7 +259,7 @@ class GRiDCodeGenerator:
         self.gen_add_code_lines(["const int ID_DU_MAX_SHARED_MEM_COUNT = " + str(count) + ";",
                                  "const int FD_DU_MAX_SHARED_MEM_COUNT = " + str(count) + ";",
                                  "// (reference bookkeeping) derivative columns that are structurally non-zero: dv/da " + str(dva_cols) + ", df " + str(df_cols)])
-        self.gen_add_code_line("#define GRID_HAS_IDSVA_SO %d // the second-order inverse-dynamics derivatives are emitted for serial revolute chains" % (1 if self.gen_idsva_so_available() else 0))
+        self.gen_add_code_line("#define GRID_HAS_IDSVA_SO %d // second-order derivatives (idsva_so, fdsva_so): emitted for revolute-joint robots whose 4 n^3 record fits the LDS staging" % (1 if self.gen_idsva_so_available() else 0))
         if self.gen_idsva_so_available():
             sl_, scr_, stg_, thr_ = self.gen_idsva_so_lds_layout()
             self.gen_add_code_lines(["const int IDSVA_SO_SUGGESTED_THREADS = %d; // idsva_so stages the 4 n^3 record of every solve in LDS: fewer solves per block" % thr_,
@@ -401,7 +401,7 @@ class GRiDCodeGenerator:
                       "    __global__ aba_kernel<T>(T *d_qdd, const T *d_q_qd_tau, const int stride_q_qd, const robotModel<T> *d_robotModel, const T gravity, const int NUM_TIMESTEPS)",
                       "    __host__   aba<T>(gridData<T> *hd_data, const robotModel<T> *d_robotModel, const T gravity, const int num_timesteps, const dim3 block_dimms, const dim3 thread_dimms, hipStream_t *streams)",
                       ""] + ([
-                      "    second order (this robot is a serial revolute chain; launch with IDSVA_SO_/FDSVA_SO_SUGGESTED_THREADS threads and the matching *_DYNAMIC_SHARED_MEM_COUNT):",
+                      "    second order (launch with IDSVA_SO_/FDSVA_SO_SUGGESTED_THREADS threads; the host wrappers size the LDS from thread_dimms):",
                       "    __device__ idsva_so_device<T>(T *so, const T *s_q, const T *s_qd, [const T *s_qdd,] T *s_scratch, const robotModel<T> *d_robotModel, const T gravity, const int lane, const bool active)",
                       "    __global__ idsva_so_kernel<T>(T *d_idsva_so, const T *d_q_qd_u, const int stride_q_qd_u, [const T *d_qdd,] const robotModel<T> *d_robotModel, const T gravity, const int NUM_TIMESTEPS)",
                       "    __host__   idsva_so_host<T,USE_QDD_FLAG=false>(gridData<T> *hd_data, const robotModel<T> *d_robotModel, const T gravity, const int num_timesteps, const dim3 block_dimms, const dim3 thread_dimms, hipStream_t *streams)",

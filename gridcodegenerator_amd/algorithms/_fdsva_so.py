@@ -16,7 +16,7 @@ first-order kernels (FDSVA_SO_SUGGESTED_THREADS).
 
 Parity: PARITY UNPINNED (the reference ships no oracle or vectors); oracle/fdsva_so_oracle.py restates the reference's contraction and is
 anchored on finite differences of the pinned first-order forward-dynamics-gradient oracle.
-Scope this round: single serial chains of revolute joints, like idsva_so.
+Scope: every robot idsva_so is emitted for (gen_idsva_so_mode: serial revolute chains, and kinematic trees of revolute joints whose 4 n^3 record fits the LDS staging).
 """
 
 
@@ -97,8 +97,9 @@ def gen_fdsva_so_device(self, use_thread_group=False):
     self.gen_add_code_line("__device__ __forceinline__")
     self.gen_add_code_line("void fdsva_so_device(T *df2, T *s_df_du, T *s_idsva_so, const T *s_q, const T *s_qd, const T *s_u, T *s_work, const robotModel<T> *d_robotModel, const T gravity, const int lane, const bool active) {", True)
     self.gen_add_code_line("T *s_qdd = &s_work[GRID_OFF_QDD]; T *s_Minv = &s_work[GRID_OFF_MINV];")
+    self.gen_add_code_line("// (the gradient comes first: it uses the workspace freely - the M^-1 slot as scratch, on branched robots its own layout - so qdd and M^-1 are produced after it)")
+    self.gen_add_code_line("forward_dynamics_gradient_device<T>(s_df_du, s_q, s_qd, s_u, s_work, d_robotModel, gravity, lane);")
     self.gen_add_code_line("forward_dynamics_device<T>(s_qdd, s_q, s_qd, s_u, s_work, d_robotModel, gravity, lane);")
-    self.gen_add_code_line("forward_dynamics_gradient_device<T>(s_df_du, s_q, s_qd, s_u, s_work, d_robotModel, gravity, lane); // (uses the M^-1 slot as scratch: M^-1 comes after it)")
     self.gen_add_code_line("direct_minv_device<T>(s_Minv, s_q, s_work, d_robotModel, lane);")
     self.gen_add_code_line("idsva_so_device<T>(s_idsva_so, s_q, s_qd, s_qdd, &s_work[GRID_OFF_X], d_robotModel, gravity, lane, true);")
     self.gen_add_sync(use_thread_group)

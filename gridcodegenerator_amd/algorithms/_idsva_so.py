@@ -23,24 +23,47 @@ Parity: the reference ships no oracle or vectors for this algorithm (PARITY UNPI
 the reference's emitter, which is itself anchored on finite differences of the pinned first-order oracle.
 Scope this round: single serial chains of revolute joints (self.tip_frame and one chain); other robots do not get the idsva_so surface.
 """
-from ._tip_frame_gradient import _chain_step, _emit_bias, _emit_chain_decls, _emit_link_constants_load, _emit_link_setup
+from ._tip_frame_gradient import _chain_step, _emit_bias, _emit_body_terms, _emit_chain_decls, _emit_link_constants_load, _emit_link_inertia, _emit_link_setup
+
+
+def gen_idsva_so_mode(self):
+    """"chain": a single serial chain of revolute joints - the tip-frame formulation (lane scans, no LDS hand-offs in the set-up);
+    "tree": any other fixed-base robot with revolute joints whose 4 n^3 record fits the LDS staging - one common (base) frame, the kinematics
+    and the subtree composites travel level by level through LDS (reference: get_parent_id tables, algorithms/_idsva_so.py:171-193,264-284,320-340);
+    None: not emitted (prismatic joints; records beyond the LDS of a CU, e.g. 30 joints: 432 KB per solve - the reference's own kernel keeps
+    4 n^3 + 390 n + 36 |pairs| values in shared memory, ~500 KB there, and cannot be launched on any GPU either)."""
+    if getattr(self, "tip_frame", False) and self.tip_nseg == 1:
+        return "chain"
+    m = self.model
+    if self.cols_per_lane != 2 or any(s_ >= 3 for s_ in m.S_index):
+        return None
+    n, G = m.n, self.lanes_per_solve
+    if (28 * n + 4 * n + 16 + 4 * n * n * n) * 4 > 150 * 1024:
+        return None
+    return "tree"
 
 
 def gen_idsva_so_available(self):
-    return bool(getattr(self, "tip_frame", False) and self.tip_nseg == 1)
+    return self.gen_idsva_so_mode() is not None
 
 
 def gen_idsva_so_inner_temp_mem_size(self):
-    return 0  # one 20-value record per joint inside the scratch area (it re-uses the X(q) block)
+    return 0  # one record per joint inside the scratch area (it re-uses the X(q) block)
+
+
+def gen_idsva_so_rec(self):
+    """Values per joint of the scratch area behind q | qd | qdd: 20 = [S | Pd | Pdd] records (chain); the tree form also parks the level-by-level
+    hand-off records there: [R(9) p(3) v(6) a(6)] = 24 on the way down, [I^C(10) B^C(12) f^C(6)] = 28 on the way up."""
+    return 28 if self.gen_idsva_so_mode() == "tree" else 20
 
 
 def gen_idsva_so_lds_layout(self):
-    """LDS of the idsva_so kernels: a compact per-solve slice [q | qd | qdd (padded) | scratch = X(q) / per-joint records (20 n) | qdd zeros] and,
+    """LDS of the idsva_so kernels: a compact per-solve slice [q | qd | qdd (padded) | scratch = X(q) / per-joint records | qdd zeros] and,
     behind the block's slices, the 4 n^3 output tensors of every solve (staged so that the record leaves with coalesced 16-byte stores:
     scattered 4-byte global stores were measured at 4.7x the cost of the arithmetic).  Returns (slice, scratch, staging, threads)."""
     n, G = self.model.n, self.lanes_per_solve
     pad4 = lambda x: (x + 3) // 4 * 4
-    scratch = 20 * n + pad4(n)
+    scratch = self.gen_idsva_so_rec() * n + pad4(n)
     sl = pad4(3 * n) + scratch
     if (sl // 4) % 2 == 0:
         sl += 4
@@ -51,33 +74,39 @@ def gen_idsva_so_lds_layout(self):
     return sl, scratch, stage, threads
 
 
+def gen_idsva_so_tree_tables(self):
+    """Per-lane constants of the tree form.  floats (16 per lane, appended to grid_model_constants): Ic (6, about the centre of mass), c (3), m,
+    damping, axis, then the origin of the joint's frame in its parent's coordinates (3) and a pad.  ints (K = 4 + max children per lane):
+    parent, tree level, subtree size, number of children, child ids."""
+    m = self.model
+    n, G = m.n, self.lanes_per_solve
+    Lc = self.gen_tip_frame_link_constants()[:12 * G]
+    fl = []
+    for j in range(G):
+        fl += Lc[12 * j:12 * j + 12]
+        fl += [float(x) for x in self.gen_tip_frame_joint_offset(j)] + [0.0] if j < n else [0.0] * 4
+    maxc = max(1, max(len(c) for c in m.children))
+    K = 4 + maxc
+    it = []
+    for j in range(G):
+        if j < n:
+            it += [m.parent[j], m.depth[j], len(m.subtree[j]), len(m.children[j])] + list(m.children[j]) + [-1] * (maxc - len(m.children[j]))
+        else:
+            it += [-1, -1, 0, 0] + [-1] * maxc
+    return fl, it, K, maxc
+
+
 def gen_idsva_so_inner_function_call(self, use_thread_group=False, use_qdd_input=False, updated_var_names=None):
     self.gen_add_code_line("idsva_so_inner<T>(so, s_qd, s_qdd, s_X, d_robotModel, gravity, lane, active);")
 
 
 def gen_idsva_so_inner(self, use_thread_group=False, use_qdd_input=False):
-    n = self.model.n
-    n2, n3 = n * n, n * n * n
-    self.gen_add_func_doc("Computes the second order derivatives of inverse dynamics",
-                          ["serial revolute chains; computed in the frame of the tip link, lane c owns the subtree joint of every (joint, ancestor, subtree) triple",
-                           "so = [d2tau_dq2 | d2tau_dqd2 | d2tau_dvdq | dM_dq], each n x n x n with [i][j][k] at i*n*n + j*n + k (reference algorithms/_idsva_so.py:204-208);",
-                           "d2tau_dvdq[i][j][k] = d2 tau_i / dq_j dqd_k, dM_dq[i][j][k] = d M_ik / dq_j.  Every entry is written exactly once; `so` may be global or LDS memory"],
-                          ["so is the output record of this solve (4*NUM_JOINTS^3 values)", "s_qd is the vector of joint velocities in LDS",
-                           "s_qdd is the vector of joint accelerations in LDS", "s_X is this solve's compact X(q) storage; it is overwritten by the per-joint records [S | Pd | Pdd]",
-                           "d_robotModel is the pointer to the initialized model specific helpers on the GPU", "gravity is the gravity constant",
-                           "lane is the caller's lane index inside the solve's lane group", "active is false for lane groups without a solve (they compute but do not store)"], None)
-    self.gen_add_code_line("template <typename T>")
-    self.gen_add_code_line("__device__ __forceinline__")
-    self.gen_add_code_line("void idsva_so_inner(T *__restrict__ so, const T *__restrict__ s_qd, const T *__restrict__ s_qdd, T *__restrict__ s_X, const robotModel<T> *d_robotModel, const T gravity, const int lane, const bool active) {", True)
-    _emit_link_constants_load(self)
-    _emit_chain_decls(self)
-    for i in range(self.tip_L - 1, -1, -1):
-        _chain_step(self, i)
-    self.gen_add_sync(use_thread_group)  # every lane is done with s_X before the records overwrite it
-    _emit_link_setup(self)
-    self.gen_add_code_line("const T qdd = (lane < %d) ? s_qdd[lane] : static_cast<T>(0);" % n)
-    _emit_bias(self, True)
-    lines = """
+    if self.gen_idsva_so_mode() == "tree":
+        return gen_idsva_so_inner_tree(self, use_thread_group)
+    return gen_idsva_so_inner_chain(self, use_thread_group)
+
+
+_SO_PREP = """
 T Pdd[6]; grid_mxm(Pdd, a, S); grid_mxm_peq(Pdd, v, Pd);
 // per-lane vectors of the reference's backward pass (:508-526): T1 = I^C S, T2 = -(B^C)^T S (bottom half zero), T3, T4, and I^C Pd
 T T1[6], T2[3], T3[6], T4[6], ICPd[6];
@@ -97,16 +126,10 @@ grid_wave_sync();
 const bool own = active && (lane < @N@)@NOSTORE@;
 T *q2 = so, *qd2 = so + @N3@, *vq = so + 2*@N3@, *mq = so + 3*@N3@;
 const int c = lane;
-// structurally zero entries of dM_dq: dM_ik/dq_j with j <= min(i, k); the owner lane (largest index) writes them first
-#pragma unroll 1
-for (int b = 0; b < @N@; b++) {
-    for (int e = 0; e <= b; e++) {
-        if (own && b <= c) { mq[(c*@N@ + e)*@N@ + b] = static_cast<T>(0); mq[(b*@N@ + e)*@N@ + c] = static_cast<T>(0); }
-    }
-}
-// main loops: joint m supplies the vectors this lane's operators act on, joint l the vector the results are dotted with
-#pragma unroll 1
-for (int m = 0; m < @N@; m++) {
+"""
+
+# operators of lane c applied to the vectors of joint m (identical for chains and trees)
+_SO_OPERATORS = """
     T yS[6], yP[6], yPP[6];
     #pragma unroll
     for (int r = 0; r < 6; r++) { yS[r] = s_X[20*m + r]; yP[r] = s_X[20*m + 6 + r]; yPP[r] = s_X[20*m + 12 + r]; }
@@ -143,16 +166,20 @@ for (int m = 0; m < @N@; m++) {
         for (int r = 0; r < 6; r++) { d2P[r] = -u[r] - w[r]; }
         grid_fxv_peq(d2P, Pd, IyP); grid_fxv_peq(d2P, yP, ICPd); grid_bmul(t, BC, yP); grid_fxv_peq(d2P, S, t);
     }
-    #pragma unroll @UNROLL_L@
-    for (int l = 0; l < @N@; l++) {
+"""
+
+_SO_X = """
         T xS[6], xP[6];
         #pragma unroll
         for (int r = 0; r < 6; r++) { xS[r] = s_X[20*l + r]; xP[r] = s_X[20*l + 6 + r]; }
         const T x_d1S = grid_dot6(xS, d1S), x_d3S = grid_dot6(xS, d3S), x_d2S = grid_dot6(xS, d2S), x_d4S = grid_dot6(xS, d4S);
         const T x_d1P = grid_dot6(xS, d1P), x_d3P = grid_dot6(xS, d3P), x_d2P = grid_dot6(xS, d2P), x_d1PP = grid_dot6(xS, d1PP);
-        if (l >= m) { // joint j = l, ancestor an = m (reference phases t1..t5 and the p1/p2 terms, :566-710, :876-886)
+"""
+
+# joint j = l, ancestor-or-self an = m (reference phases t1..t5 and the p1/p2 terms, :566-710, :876-886); @SUB@ = "c is in the subtree of j (incl. j)"
+_SO_CASE_A = """
             const int j = l, an = m;
-            const bool ok = own && (c >= j), ne = ok && (c != j);
+            const bool ok = own && @SUB@, ne = ok && (c != j);
             T p1[6], p2[6]; grid_mxm(p1, yP, xS); grid_mxm(p2, yPP, xS);
             const T pa = -(p1[0]*T2[0] + p1[1]*T2[1] + p1[2]*T2[2]) + grid_dot6(p2, T1);
             const T vq_ = -grid_dot6(xP, d3P) + pa;
@@ -160,7 +187,7 @@ for (int m = 0; m < @N@; m++) {
             if (ok) {
                 q2[(c*@N@ + an)*@N@ + j] = vq_;
                 vq[(c*@N@ + an)*@N@ + j] = -x_d3P;
-                if (an < j) { q2[(c*@N@ + j)*@N@ + an] = vq_; qd2[(c*@N@ + j)*@N@ + an] = -x_d3S; qd2[(c*@N@ + an)*@N@ + j] = -x_d3S; }
+                if (an != j) { q2[(c*@N@ + j)*@N@ + an] = vq_; qd2[(c*@N@ + j)*@N@ + an] = -x_d3S; qd2[(c*@N@ + an)*@N@ + j] = -x_d3S; }
                 else { qd2[(c*@N@ + an)*@N@ + j] = -x_d1S; }
             }
             if (ne) {
@@ -169,14 +196,18 @@ for (int m = 0; m < @N@; m++) {
                 qd2[(j*@N@ + c)*@N@ + an] = x_d3S; qd2[(j*@N@ + an)*@N@ + c] = x_d3S;
                 vq[(j*@N@ + c)*@N@ + an] = x_d2S + static_cast<T>(2)*x_d1P;
             }
-        }
-        if (l <= m) { // joint j = m, ancestor an = l: second half of the reference's t8 phase (:815-816)
+"""
+
+# joint j = m, ancestor-or-self an = l: second half of the reference's t8 phase (:815-816); @SUBX@ = "c is in the subtree of j, c != j"
+_SO_CASE_B = """
             const int j = m, an = l;
-            if (own && (c > j)) { mq[(an*@N@ + c)*@N@ + j] = x_d1S; mq[(j*@N@ + c)*@N@ + an] = x_d1S; }
-        }
-        if (l < m) { // joint j = m, ancestor an = l < j (reference phases t6..t9, the p3..p6 terms, :725-911)
+            if (own && @SUBX@) { mq[(an*@N@ + c)*@N@ + j] = x_d1S; mq[(j*@N@ + c)*@N@ + an] = x_d1S; }
+"""
+
+# joint j = m, proper ancestor an = l (reference phases t6..t9, the p3..p6 terms, :725-911)
+_SO_CASE_C = """
             const int j = m, an = l;
-            const bool ok = own && (c >= j), ne = ok && (c != j);
+            const bool ok = own && @SUB@, ne = ok && (c != j);
             T p1[6], p3[6], p4[6]; grid_mxm(p1, xP, yS); grid_mxm(p3, xS, yS); grid_mxm(p4, yP, xS);
             #pragma unroll
             for (int r = 0; r < 6; r++) { p4[r] = static_cast<T>(2)*(p1[r] - p4[r]); }
@@ -198,15 +229,194 @@ for (int m = 0; m < @N@; m++) {
                 T t[6]; grid_zero6(t); grid_fxv_peq(t, S, T1);
                 qd2[(an*@N@ + j)*@N@ + j] = grid_dot6(T1, p3) + grid_dot6(xS, t);
             }
-        }
+"""
+
+
+def _so_emit(self, text, **subs):
+    n = self.model.n
+    text = text.replace("@N3@", str(n * n * n)).replace("@N@", str(n))
+    text = text.replace("@NOSTORE@", " && (gravity < static_cast<T>(-1e30))" if self.tuning["debug_stop"] == 30 else "")  # timing ablation: everything computed, nothing stored
+    for k, v in subs.items():
+        text = text.replace("@" + k + "@", v)
+    for line in text.strip("\n").split("\n"):
+        self.gen_add_code_line(line)
+
+
+def _so_inner_header(self):
+    n = self.model.n
+    form = "serial revolute chains; computed in the frame of the tip link" if self.gen_idsva_so_mode() == "chain" else \
+        "kinematic trees of revolute joints; computed in the base frame, kinematics and subtree composites handed level by level through LDS"
+    self.gen_add_func_doc("Computes the second order derivatives of inverse dynamics",
+                          [form + ", lane c owns the subtree joint of every (joint, ancestor, subtree) triple",
+                           "so = [d2tau_dq2 | d2tau_dqd2 | d2tau_dvdq | dM_dq], each n x n x n with [i][j][k] at i*n*n + j*n + k (reference algorithms/_idsva_so.py:204-208);",
+                           "d2tau_dvdq[i][j][k] = d2 tau_i / dq_j dqd_k, dM_dq[i][j][k] = d M_ik / dq_j.  Every entry is written exactly once (trees: after a zero fill of the record by the same wave); `so` may be LDS" +
+                           (" or global memory" if self.gen_idsva_so_mode() == "chain" else "")],
+                          ["so is the output record of this solve (4*NUM_JOINTS^3 values)", "s_qd is the vector of joint velocities in LDS",
+                           "s_qdd is the vector of joint accelerations in LDS", "s_X is this solve's scratch: compact X(q) storage on entry; it is overwritten by the per-joint records",
+                           "d_robotModel is the pointer to the initialized model specific helpers on the GPU", "gravity is the gravity constant",
+                           "lane is the caller's lane index inside the solve's lane group", "active is false for lane groups without a solve (they compute but do not store)"], None)
+    self.gen_add_code_line("template <typename T>")
+    self.gen_add_code_line("__device__ __forceinline__")
+    self.gen_add_code_line("void idsva_so_inner(T *__restrict__ so, const T *__restrict__ s_qd, const T *__restrict__ s_qdd, T *__restrict__ s_X, const robotModel<T> *d_robotModel, const T gravity, const int lane, const bool active) {", True)
+
+
+def gen_idsva_so_inner_chain(self, use_thread_group=False):
+    n = self.model.n
+    _so_inner_header(self)
+    _emit_link_constants_load(self)
+    _emit_chain_decls(self)
+    for i in range(self.tip_L - 1, -1, -1):
+        _chain_step(self, i)
+    self.gen_add_sync(use_thread_group)  # every lane is done with s_X before the records overwrite it
+    _emit_link_setup(self)
+    self.gen_add_code_line("const T qdd = (lane < %d) ? s_qdd[lane] : static_cast<T>(0);" % n)
+    _emit_bias(self, True)
+    _so_emit(self, _SO_PREP)
+    _so_emit(self, """
+// structurally zero entries of dM_dq: dM_ik/dq_j with j <= min(i, k); the owner lane (largest index) writes them first
+#pragma unroll 1
+for (int b = 0; b < @N@; b++) {
+    for (int e = 0; e <= b; e++) {
+        if (own && b <= c) { mq[(c*@N@ + e)*@N@ + b] = static_cast<T>(0); mq[(b*@N@ + e)*@N@ + c] = static_cast<T>(0); }
     }
 }
-""".replace("@N@", str(n)).replace("@N3@", str(n3))
-    # timing ablation only (GRID_DEBUG_STOP=30): everything is computed, (almost) nothing is stored
-    lines = lines.replace("@UNROLL_L@", str(self.tuning["so_unroll"] or n))  # tuning knob: inner-loop unrolling of idsva_so (full: -7 % vs none on the 7-DoF arm)
-    lines = lines.replace("@NOSTORE@", " && (gravity < static_cast<T>(-1e30))" if self.tuning["debug_stop"] == 30 else "")
-    for line in lines.strip("\n").split("\n"):
-        self.gen_add_code_line(line)
+// main loops: joint m supplies the vectors this lane's operators act on, joint l the vector the results are dotted with
+#pragma unroll 1
+for (int m = 0; m < @N@; m++) {""")
+    _so_emit(self, _SO_OPERATORS)
+    _so_emit(self, "    #pragma unroll @UNROLL_L@\n    for (int l = 0; l < @N@; l++) {", UNROLL_L=str(self.tuning["so_unroll"] or n))
+    _so_emit(self, _SO_X)
+    _so_emit(self, "        if (l >= m) {")
+    _so_emit(self, _SO_CASE_A, SUB="(c >= j)")
+    _so_emit(self, "        }\n        if (l <= m) {")
+    _so_emit(self, _SO_CASE_B, SUBX="(c > j)")
+    _so_emit(self, "        }\n        if (l < m) {")
+    _so_emit(self, _SO_CASE_C, SUB="(c >= j)")
+    _so_emit(self, "        }\n    }\n}")
+    self.gen_add_end_function()
+
+
+def gen_idsva_so_inner_tree(self, use_thread_group=False):
+    """Tree form.  Same operators and the same merged per-entry formulas as the chain form; what changes is where the per-joint quantities come from
+    (level-by-level propagation through LDS instead of lane scans, all in the base frame) and which (m, l) pairs are visited: the reference's triples
+    (joint j, ancestor-or-self an, subtree member c) live on ONE root path, so for every m only its subtree (a contiguous id range in DFS pre-order)
+    and its ancestors (a parent walk) are visited - unrelated joints contribute structural zeros, which a zero fill of the record provides."""
+    m_ = self.model
+    n = m_.n
+    fl, it, K, maxc = self.gen_idsva_so_tree_tables()
+    depth = max(m_.depth)
+    off = self.so_tree_tab_offset
+    _so_inner_header(self)
+    A = self.gen_add_code_line
+    A("const int *tp = &grid_so_tree_topology[%d*lane]; // this lane's row: parent, level, subtree size, number of children, children" % K)
+    A("const int par = tp[0], lev = tp[1];")
+    A("T Lc[16]; // link constants: Ic (6, about the centre of mass), c (3), m, damping, axis | origin of the joint frame in its parent's coordinates (3)")
+    A("{ const T *d_L = &grid_model_constants(static_cast<const T *>(nullptr))[%d + 16*lane]; (void)d_robotModel;" % off)
+    A("  #pragma unroll")
+    A("  for (int r = 0; r < 16; r++) { Lc[r] = d_L[r]; } }")
+    A("const bool has = lane < %d;" % n)
+    A("T E[9]; // rotation block of this joint's X(q) (parent -> child coordinates), fetched before the scratch is re-used")
+    A("#pragma unroll")
+    A("for (int r = 0; r < 9; r++) { E[r] = has ? s_X[GRID_X_STRIDE*lane + r] : static_cast<T>(0); }")
+    A("const T qd = has ? s_qd[lane] : static_cast<T>(0), qdd = has ? s_qdd[lane] : static_cast<T>(0);")
+    self.gen_add_sync(use_thread_group)
+    A("// zero fill of the output record: most of its 4 n^3 entries are structural zeros of the tree (joints on different root paths)")
+    A("if (active) { for (int e = lane; e < %d; e += GRID_LANES_PER_SOLVE) { so[e] = static_cast<T>(0); } }" % (4 * n ** 3))
+    A("// top-down, one tree level at a time: pose of the link frame in the base frame (myR: link -> base coordinates, myp: its origin), joint axis S,")
+    A("// spatial velocity v, acceleration a (with the gravity term) and Pd = v_parent x S; a joint's record [myR | myp | v | a] waits in LDS for its children")
+    A("T myR[9], myp[3], S[6], v[6], a[6], Pd[6];")
+    A("#pragma unroll")
+    A("for (int r = 0; r < 6; r++) { S[r] = v[r] = a[r] = Pd[r] = static_cast<T>(0); }")
+    A("#pragma unroll")
+    A("for (int r = 0; r < 9; r++) { myR[r] = static_cast<T>(0); }")
+    A("myp[0] = myp[1] = myp[2] = static_cast<T>(0);")
+    A("#pragma unroll 1")
+    A("for (int L = 0; L <= %d; L++) {" % depth, True)
+    A("if (has && lev == L) {", True)
+    A("T Rp[9] = {static_cast<T>(1), static_cast<T>(0), static_cast<T>(0), static_cast<T>(0), static_cast<T>(1), static_cast<T>(0), static_cast<T>(0), static_cast<T>(0), static_cast<T>(1)};")
+    A("T pp[3] = {static_cast<T>(0), static_cast<T>(0), static_cast<T>(0)}, vp[6], ap[6];")
+    A("#pragma unroll")
+    A("for (int r = 0; r < 6; r++) { vp[r] = static_cast<T>(0); ap[r] = static_cast<T>(0); }")
+    A("ap[5] = gravity; // base acceleration (0, 0, g): gravity is passed positive (reference algorithms/_inverse_dynamics.py:123)")
+    A("if (par >= 0) {", True)
+    A("const T *rec = &s_X[28*par];")
+    A("#pragma unroll")
+    A("for (int r = 0; r < 9; r++) { Rp[r] = rec[r]; }")
+    A("#pragma unroll")
+    A("for (int r = 0; r < 3; r++) { pp[r] = rec[9 + r]; }")
+    A("#pragma unroll")
+    A("for (int r = 0; r < 6; r++) { vp[r] = rec[12 + r]; ap[r] = rec[18 + r]; }")
+    self.gen_add_end_control_flow()
+    A("#pragma unroll")
+    A("for (int r = 0; r < 3; r++) { // myR = Rp E^T, myp = pp + Rp r_joint", True)
+    A("#pragma unroll")
+    A("for (int cc = 0; cc < 3; cc++) { myR[3*r + cc] = Rp[3*r]*E[3*cc] + Rp[3*r+1]*E[3*cc+1] + Rp[3*r+2]*E[3*cc+2]; }")
+    A("myp[r] = pp[r] + Rp[3*r]*Lc[12] + Rp[3*r+1]*Lc[13] + Rp[3*r+2]*Lc[14];")
+    self.gen_add_end_control_flow()
+    A("{ const int ax = static_cast<int>(Lc[11]);")
+    A("  #pragma unroll")
+    A("  for (int r = 0; r < 3; r++) { S[r] = (ax == 0) ? myR[3*r] : ((ax == 1) ? myR[3*r+1] : myR[3*r+2]); } }")
+    A("S[3] = myp[1]*S[2] - myp[2]*S[1]; S[4] = myp[2]*S[0] - myp[0]*S[2]; S[5] = myp[0]*S[1] - myp[1]*S[0];")
+    A("grid_mxm(Pd, vp, S);")
+    A("#pragma unroll")
+    A("for (int r = 0; r < 6; r++) { v[r] = vp[r] + S[r]*qd; a[r] = ap[r] + Pd[r]*qd + S[r]*qdd; }")
+    A("T *out = &s_X[28*lane];")
+    A("#pragma unroll")
+    A("for (int r = 0; r < 9; r++) { out[r] = myR[r]; }")
+    A("#pragma unroll")
+    A("for (int r = 0; r < 3; r++) { out[9 + r] = myp[r]; }")
+    A("#pragma unroll")
+    A("for (int r = 0; r < 6; r++) { out[12 + r] = v[r]; out[18 + r] = a[r]; }")
+    self.gen_add_end_control_flow()
+    self.gen_add_sync(use_thread_group)
+    self.gen_add_end_control_flow()
+    _emit_link_inertia(self)
+    _emit_body_terms(self)
+    A("#pragma unroll")
+    A("for (int r = 0; r < 10; r++) { IC[r] = has ? I[r] : static_cast<T>(0); }")
+    A("// bottom-up, one tree level at a time: composites over the subtree, [I^C | B^C | f^C] of a joint waits in LDS for its parent")
+    A("#pragma unroll 1")
+    A("for (int L = %d; L >= 0; L--) {" % depth, True)
+    A("if (has && lev == L) {", True)
+    A("#pragma unroll 1")
+    A("for (int ci = 0; ci < tp[3]; ci++) {", True)
+    A("const T *rec = &s_X[28*tp[4 + ci]];")
+    A("#pragma unroll")
+    A("for (int r = 0; r < 10; r++) { IC[r] += rec[r]; }")
+    A("#pragma unroll")
+    A("for (int r = 0; r < 12; r++) { BC[r] += rec[10 + r]; }")
+    A("#pragma unroll")
+    A("for (int r = 0; r < 6; r++) { fC[r] += rec[22 + r]; }")
+    self.gen_add_end_control_flow()
+    A("T *out = &s_X[28*lane];")
+    A("#pragma unroll")
+    A("for (int r = 0; r < 10; r++) { out[r] = IC[r]; }")
+    A("#pragma unroll")
+    A("for (int r = 0; r < 12; r++) { out[10 + r] = BC[r]; }")
+    A("#pragma unroll")
+    A("for (int r = 0; r < 6; r++) { out[22 + r] = fC[r]; }")
+    self.gen_add_end_control_flow()
+    self.gen_add_sync(use_thread_group)
+    self.gen_add_end_control_flow()
+    _so_emit(self, _SO_PREP)
+    sub = lambda jv: "(c >= %s && c < %s + grid_so_tree_topology[%d*%s + 2])" % (jv, jv, K, jv)
+    _so_emit(self, """
+// main loops: joint m supplies the vectors this lane's operators act on; joint l, on the same root path, the vector the results are dotted with
+#pragma unroll 1
+for (int m = 0; m < @N@; m++) {""")
+    _so_emit(self, _SO_OPERATORS)
+    _so_emit(self, "    const int m_end = m + grid_so_tree_topology[%d*m + 2];\n    #pragma unroll 1\n    for (int l = m; l < m_end; l++) { // l in the subtree of m (incl. m): joint j = l, ancestor-or-self an = m" % K)
+    _so_emit(self, _SO_X)
+    _so_emit(self, "        {")
+    _so_emit(self, _SO_CASE_A, SUB=sub("j"))
+    _so_emit(self, "        }\n    }")
+    _so_emit(self, "    #pragma unroll 1\n    for (int l = m; l >= 0; l = grid_so_tree_topology[%d*l]) { // l = m, then its ancestors: joint j = m, ancestor-or-self an = l" % K)
+    _so_emit(self, _SO_X)
+    _so_emit(self, "        {")
+    _so_emit(self, _SO_CASE_B, SUBX="(c > j && c < j + grid_so_tree_topology[%d*j + 2])" % K)
+    _so_emit(self, "        }\n        if (l != m) {")
+    _so_emit(self, _SO_CASE_C, SUB=sub("j"))
+    _so_emit(self, "        }\n    }\n}")
     self.gen_add_end_function()
 
 
@@ -226,7 +436,7 @@ def gen_idsva_so_device(self, use_thread_group=False, use_qdd_input=False):
                            "T *s_scratch, const robotModel<T> *d_robotModel, const T gravity, const int lane, const bool active) {", True)
     self.gen_add_code_line("T *s_X = s_scratch;")
     if not use_qdd_input:
-        self.gen_add_code_line("T *s_qdd = &s_scratch[%d];" % (20 * n))
+        self.gen_add_code_line("T *s_qdd = &s_scratch[%d];" % (self.gen_idsva_so_rec() * n))
         self.gen_add_code_line("if (lane < %d) { s_qdd[lane] = static_cast<T>(0); }" % n)
     self.gen_load_update_XImats_helpers_function_call(use_thread_group)
     self.gen_idsva_so_inner_function_call(use_thread_group, use_qdd_input)

@@ -293,6 +293,18 @@ def _emit_link_setup(self, kinematics=True, base_family=False):
         self.gen_add_code_line("  #pragma unroll")
         self.gen_add_code_line("  for (int r = 0; r < 3; r++) { S[r] = (ax == 0) ? myR[3*r] : ((ax == 1) ? myR[3*r+1] : myR[3*r+2]); } }")
     self.gen_add_code_line("S[3] = myp[1]*S[2] - myp[2]*S[1]; S[4] = myp[2]*S[0] - myp[0]*S[2]; S[5] = myp[0]*S[1] - myp[1]*S[0];")
+    _emit_link_inertia(self, base_family)
+    if not kinematics:
+        return
+    self.gen_add_code_line("T v[6];")
+    self.gen_add_code_line("#pragma unroll")
+    self.gen_add_code_line("for (int r = 0; r < 6; r++) { v[r] = S[r]*qd; }")
+    self.gen_add_code_line("grid_prefix_sum(v, mku); // v_j = sum over the ancestors of S_k qd_k")
+    self.gen_add_code_line("T Pd[6]; grid_mxm(Pd, v, S); // = S_j-dot")
+
+
+def _emit_link_inertia(self, base_family=False):
+    """I[10]: the lane's link inertia about the origin of the working frame, from (myR, myp) and the link constants Lc."""
     self.gen_add_code_line("T I[10]; // this link's inertia about the origin of F")
     if base_family and self.tip_jB is not None:
         self.gen_add_code_line("T IB[10], SB[3]; // ... and about pB, and the linear part of S about pB (base family, see _emit_base_family)")
@@ -326,13 +338,6 @@ def _emit_link_setup(self, kinematics=True, base_family=False):
         self.gen_add_code_line("{ const T e0 = myp[0] - pB[0], e1 = myp[1] - pB[1], e2 = myp[2] - pB[2];")
         self.gen_add_code_line("  SB[0] = e1*S[2] - e2*S[1]; SB[1] = e2*S[0] - e0*S[2]; SB[2] = e0*S[1] - e1*S[0]; }")
     self.gen_add_end_control_flow()
-    if not kinematics:
-        return
-    self.gen_add_code_line("T v[6];")
-    self.gen_add_code_line("#pragma unroll")
-    self.gen_add_code_line("for (int r = 0; r < 6; r++) { v[r] = S[r]*qd; }")
-    self.gen_add_code_line("grid_prefix_sum(v, mku); // v_j = sum over the ancestors of S_k qd_k")
-    self.gen_add_code_line("T Pd[6]; grid_mxm(Pd, v, S); // = S_j-dot")
 
 
 def _emit_bias(self, with_qdd):
@@ -345,6 +350,13 @@ def _emit_bias(self, with_qdd):
         self.gen_add_code_line("for (int r = 0; r < 6; r++) { a[r] = Pd[r]*qd; }")
     self.gen_add_code_line("grid_prefix_sum(a, mku);")
     self.gen_add_code_line("a[3] += gvec[0]; a[4] += gvec[1]; a[5] += gvec[2];")
+    _emit_body_terms(self)
+    _emit_inertia_composite(self)
+    self.gen_add_code_line("grid_suffix_sum(BC, mkd); grid_suffix_sum(fC, mkd); // composites over the links j..n-1")
+
+
+def _emit_body_terms(self):
+    """Per link, from I (10), v, a: the force f = I a + v x* I v (into fC) and the body-level Coriolis matrix B(I, v) (into BC); declares IC, BC, fC."""
     self.gen_add_code_line("T IC[10], BC[12], fC[6];")
     self.gen_add_code_line("{", True)
     self.gen_add_code_line("T Iv[6]; grid_rbi_mul(Iv, I, v); // [n; l]: the link's momentum")
@@ -363,8 +375,6 @@ def _emit_bias(self, with_qdd):
     self.gen_add_code_line("#pragma unroll")
     self.gen_add_code_line("for (int r = 0; r < 6; r++) { BC[6 + r] = Iv[r]; }")
     self.gen_add_end_control_flow()
-    _emit_inertia_composite(self)
-    self.gen_add_code_line("grid_suffix_sum(BC, mkd); grid_suffix_sum(fC, mkd); // composites over the links j..n-1")
 
 
 def _emit_inertia_composite(self):

@@ -93,6 +93,12 @@ def gen_model_constant_table(self):
     if getattr(self, "branch_frame", False):  # per-lane rows of the branch-frame gradient path
         assert len(vals) == self.branch_tab_offset
         vals += self.gen_branch_frame_constants()
+    if self.gen_idsva_so_mode() == "tree":  # per-lane rows of the tree form of the second-order kernels (algorithms/_idsva_so.py)
+        fl, it, K, _ = self.gen_idsva_so_tree_tables()
+        self.so_tree_tab_offset = len(vals)
+        vals += fl
+        self.gen_add_code_line("// tree topology for the second-order kernels, %d ints per lane: parent, tree level, subtree size, number of children, children" % K)
+        self.gen_add_code_line("__device__ const int grid_so_tree_topology[%d] = {%s};" % (len(it), ", ".join(str(int(x)) for x in it)))
     for ctype, sfx in (("float", "f"), ("double", "")):
         self.gen_add_code_line("__device__ const %s grid_model_constants_%s[%d] = {" % (ctype, ctype, len(vals)), True)
         for k in range(0, len(vals), 6):

@@ -45,7 +45,7 @@ def test_emitted_surface(code):
                  "NUM_JOINTS = 12", "FD_DU_DYNAMIC_SHARED_MEM_COUNT", "FD_DU_MAX_SHARED_MEM_COUNT", "SUGGESTED_THREADS", "#define XIMAT_SIZE 36",
                  "gpuErrchk", "USE_QDD_MINV_FLAG", "USE_QDD_FLAG", "USE_COMPRESSED_MEM"):
         assert name in code, name
-    assert "GRID_HAS_IDSVA_SO 0" in code and "idsva_so_kernel" not in code  # the second-order surface is emitted for serial revolute chains only
+    assert "GRID_HAS_IDSVA_SO 1" in code and "idsva_so_kernel" in code and "fdsva_so_kernel" in code  # trees get the tree form of the second-order surface
     assert "cuda_runtime" not in code and "cudaMalloc" not in code and "cudaStream_t" not in code  # HIP only, no CUDA shims
     assert "__syncthreads" not in code  # wave-level hand-offs only
 

@@ -298,9 +298,9 @@ def test_non_default_generation_variants_on_gpu(tuning, torch_cuda, golden, tmp_
     lib.close()
 
 
-@pytest.mark.parametrize("name", ["iiwa14", "arm6", "chain12", "chain8"])
+@pytest.mark.parametrize("name", ["iiwa14", "arm6", "chain12", "chain8", "hyq", "tree12"])
 def test_idsva_so_matches_the_restated_reference_algorithm(name, torch_cuda, libs, golden):
-    """SURVEY.md section 8(f) rank 3 (serial revolute chains): second-order inverse-dynamics derivatives on the GPU vs the NumPy restatement of the
+    """SURVEY.md section 8(f) rank 3 (serial chains: tip-frame form; the quadruped and the 12-DoF tree: tree form): second-order inverse-dynamics derivatives on the GPU vs the NumPy restatement of the
     reference's emitter (oracle/idsva_so_oracle.py - parity unpinned, anchored on finite differences of the pinned first-order oracle)."""
     from gridcodegenerator_amd.robot import DuckRobot
     from oracle.idsva_so_oracle import idsva_so
@@ -334,16 +334,18 @@ def test_idsva_so_matches_the_restated_reference_algorithm(name, torch_cuda, lib
     assert np.array_equal(out2.cpu().numpy(), got)
 
 
-def test_idsva_so_is_refused_for_branched_robots(torch_cuda, libs):
+def test_second_order_is_refused_where_the_record_does_not_fit(torch_cuda, libs):
+    """30 joints: 4 n^3 = 432 KB per solve does not fit the LDS of a CU (the reference's kernel would need ~500 KB of shared memory)."""
     from gridcodegenerator_amd.runtime import GridError
 
     torch = torch_cuda
-    lib = libs("hyq")
+    lib = libs("atlas")
+    assert not lib.has_second_order
     with pytest.raises(GridError):
-        lib.idsva_so_device(torch.zeros((1, 36), device="cuda"), None, 1, torch.zeros((1, 4 * 12 ** 3), device="cuda"))
+        lib.idsva_so_device(torch.zeros((1, 90), device="cuda"), None, 1, torch.zeros((1, 4), device="cuda"))
 
 
-@pytest.mark.parametrize("name", ["iiwa14", "arm6", "chain12", "chain8"])
+@pytest.mark.parametrize("name", ["iiwa14", "arm6", "chain12", "chain8", "hyq", "tree12"])
 def test_fdsva_so_matches_the_restated_reference_algorithm(name, torch_cuda, libs, golden):
     """Second half of SURVEY.md section 8(f) rank 3 (serial revolute chains): second-order forward-dynamics derivatives on the GPU vs the NumPy
     restatements of the reference's idsva_so + fdsva_so emitters fed by the pinned first-order oracle (parity unpinned)."""
@@ -537,10 +539,12 @@ def test_large_batch_component_kernels_after_lds_reuse(torch_cuda, libs):
     lib.close()
 
 
-def test_generated_host_api_of_a_chain_first_and_second_order_float_and_double(torch_cuda, golden, tmp_path):
-    """The generated host API of a serial-chain robot (tip-frame path) for T = float and T = double: forward_dynamics_gradient<T>, forward_dynamics<T>,
-    idsva_so_host<T, true>, fdsva_so<T>.  The double instantiations must agree with the fp64 oracles to rounding level - that pins the generated
-    algorithms (incl. the DPP scans on 64-bit values and the register factorisation) independently of fp32 effects."""
+@pytest.mark.parametrize("name,so_threads_f64", [("iiwa14", 0), ("hyq", 32)])
+def test_generated_host_api_first_and_second_order_float_and_double(name, so_threads_f64, torch_cuda, golden, tmp_path):
+    """The generated host API of a serial-chain robot (tip-frame path, chain form of the second order) and of a branched one (a forest: tip-frame path per limb, tree
+    form of the second order) for T = float and T = double: forward_dynamics_gradient<T>, forward_dynamics<T>, idsva_so_host<T, true>, fdsva_so<T>.
+    The double instantiations must agree with the fp64 oracles to rounding level - that pins the generated algorithms (incl. the DPP scans on 64-bit
+    values, the register factorisation, the level-by-level tree propagation) independently of fp32 effects."""
     import os
     import shutil
     import subprocess
@@ -551,7 +555,6 @@ def test_generated_host_api_of_a_chain_first_and_second_order_float_and_double(t
     from oracle.idsva_so_oracle import idsva_so
     from oracle.rbd_oracle import Oracle
 
-    name = "iiwa14"
     g = golden(name)
     n, N = g["q"].shape[1], 4
     gen_dir = tmp_path / "gen"
@@ -562,7 +565,7 @@ def test_generated_host_api_of_a_chain_first_and_second_order_float_and_double(t
     subprocess.check_call([shutil.which("hipcc") or "/opt/rocm/bin/hipcc"] + flags + ["-I" + str(gen_dir), src, "-o", exe])
     x = np.hstack([g["q"], g["qd"], g["u"]]).astype(np.float64)[:N]
     (tmp_path / "in.bin").write_bytes(x.tobytes())
-    out = subprocess.check_output([exe, str(tmp_path / "in.bin"), str(N), str(tmp_path / "o")], text=True)
+    out = subprocess.check_output([exe, str(tmp_path / "in.bin"), str(N), str(tmp_path / "o"), str(so_threads_f64)], text=True)
     assert "done" in out
     assert out.count("with SUGGESTED_THREADS: mismatches = 0") == 4, out  # (the second-order hosts launched with the general block size)
     robot = RobotModel.from_fixture(name)
