@@ -427,7 +427,7 @@ class GRiDCodeGenerator:
         self.gen_add_code_line("namespace " + self.file_namespace + " {", True)
         self.gen_add_constants_helpers(include_base_inertia, include_homogenous_transforms)
         self.gen_spatial_algebra_helpers()
-        if self.tip_frame or self.branch_frame:
+        if self.tip_frame or self.branch_frame or self.gen_idsva_so_mode() is not None:  # (the second-order kernels use its cross products, 10-parameter inertias, Coriolis matrices)
             self.gen_tip_frame_library()
         if self.branch_frame:
             self.gen_branch_frame_library()
