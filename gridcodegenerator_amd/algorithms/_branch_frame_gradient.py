@@ -126,7 +126,7 @@ def gen_branch_frame_plan(self):
 
 def gen_branch_frame_constants(self):
     """Table rows appended to grid_model_constants: one row per lane
-    [Ic (6) | c (3) | m | damping | axis | joint id | pos | branch length | level | branch slot | component base | shape | path length | factor base of the component | start of the joint's column in the compact M | 2 spare |
+    [Ic (6) | c (3) | m | damping | axis | joint id | pos | branch length | level | branch slot | component base | shape | path length | factor base of the component | start of the joint's column in the compact M | path step of the branch's base-origin joint (-1: none) | 1 if this lane's column of M uses the base family |
      path codes (4*joint + axis, tip -> root, -1 = none) x D | child branch slots (-1 = none) x maxchild |
      origin of every path joint's frame in its parent's coordinates x D (so that no table read depends on another one)]."""
     m = self.model
@@ -157,6 +157,12 @@ def gen_branch_frame_constants(self):
                       float(P["shape_of"][P["comp_base"][j]]), float(len(P["paths"][b]))]
         row[20] = float(P["ubase"][P["comp_base"][j]])
         row[21] = float(P["mstart"][j])
+        # base-origin family (see _tip_frame_gradient._emit_base_family): leaf branches of 5 or more joints evaluate the columns of M of their
+        # base half about the frame origin of the branch's middle joint instead of the branch tip
+        jB = len(J) // 2
+        use_b = self.tuning["base_origin"] != "off" and len(J) >= 5 and not P["kids"][b]
+        row[22] = float(len(J) - 1 - jB) if use_b else -1.0
+        row[23] = 1.0 if (use_b and J.index(j) <= jB) else 0.0
         for i in range(P["D"]):
             path = P["paths"][b]
             row[24 + i] = float(4 * path[i] + m.S_index[path[i]]) if i < len(path) else -1.0
@@ -254,6 +260,23 @@ def gen_branch_frame_library(self):
     self.gen_add_code_line("")
 
 
+# M[i][k] = S_i . t1m with the linear part of S_i taken about the reference point of column k's family: about pB it is lin - pB x w
+_MKJ_FAM = ("(Spi[0]*t1m[0] + Spi[1]*t1m[1] + Spi[2]*t1m[2]"
+            " + (fam ? Spi[3] - (pB[1]*Spi[2] - pB[2]*Spi[1]) : Spi[3])*t1m[3]"
+            " + (fam ? Spi[4] - (pB[2]*Spi[0] - pB[0]*Spi[2]) : Spi[4])*t1m[4]"
+            " + (fam ? Spi[5] - (pB[0]*Spi[1] - pB[1]*Spi[0]) : Spi[5])*t1m[5])")
+
+
+def _t1m_lines():
+    return ["T t1m[6]; // the I^C S this lane's column of M is built from: about pB for the base half of a long leaf branch, about the branch tip otherwise",
+            "{ T x[6], y[6];",
+            "  x[0] = S[0]; x[1] = S[1]; x[2] = S[2];",
+            "  { const T e0 = myp[0] - pB[0], e1 = myp[1] - pB[1], e2 = myp[2] - pB[2]; x[3] = e1*S[2] - e2*S[1]; x[4] = e2*S[0] - e0*S[2]; x[5] = e0*S[1] - e1*S[0]; }",
+            "  grid_rbi_mul(y, ICB, x);",
+            "  #pragma unroll",
+            "  for (int r = 0; r < 6; r++) { t1m[r] = fam ? y[r] : t1[r]; } }"]
+
+
 def _anc_local(sig):
     """Strict ancestors (local indices, ascending) of every joint of a component with parent signature sig."""
     out = []
@@ -347,6 +370,9 @@ def _emit_branch_inner(self, mode, use_thread_group=False):
     ptr = lambda item: "&s_%s[%d]" % ("X" if P["place"][item][0] == "x" else "SP", P["place"][item][1])
     A("T *s_Mc = %s, *s_Uc = %s + ubase, *s_G = %s, *s_trash = %s; // (s_X: valid once the frame chain is done with X(q))" % (ptr("M"), ptr("U"), ptr("G"), ptr("trash")))
     A("const int own = Lb - 1 - pos; // index of this lane's joint on the root path of its branch (tip -> root); -1 on lanes without a joint")
+    bfam = needs_M and any(r_ >= 0 for r_ in self.gen_branch_frame_constants()[22::RL])
+    if bfam:
+        A("const int iB = static_cast<int>(d_L[22]); const bool fam = d_L[23] > static_cast<T>(0.5); // base-origin family of the joint-space inertia (leaf branches of >= 5 joints)")
     A("const int li = jid - cbase;   // index of the joint inside its base-rooted component")
     A("T *s_Sp = &s_SP[%d*slot]; // joint axes along the root path of this lane's branch, in the branch frame" % (6 * D))
     A("(void)level; (void)plen; (void)s_G; (void)mstart; (void)s_Mc; (void)s_Uc; (void)s_trash; (void)shape; (void)li; (void)ubase;")
@@ -369,6 +395,8 @@ def _emit_branch_inner(self, mode, use_thread_group=False):
     A("// frames: walk the root path of this lane's branch, tip -> root")
     A("//")
     A("T myR[9], myp[3], TR[9], Tp[3], gvec[3] = {Z, Z, Z};")
+    if bfam:
+        A("T pB[3] = {Z, Z, Z}; // second reference point: the frame origin of the branch's middle joint, in the branch frame")
     A("{", True)
     ro = H + D + max(maxchild, 1)
     A("T rj[%d][3]; // origins of the path joints' frames in their parents' coordinates: all table reads issued before the first use" % D)
@@ -399,6 +427,8 @@ def _emit_branch_inner(self, mode, use_thread_group=False):
             A("for (int r = 0; r < 9; r++) { myR[r] = (own == %d) ? Rc[r] : myR[r]; }" % i)
             A("#pragma unroll")
             A("for (int r = 0; r < 3; r++) { myp[r] = (own == %d) ? pc[r] : myp[r]; }" % i)
+        if bfam and 0 < i < maxLb:
+            A("pB[0] = (iB == %d) ? pc[0] : pB[0]; pB[1] = (iB == %d) ? pc[1] : pB[1]; pB[2] = (iB == %d) ? pc[2] : pB[2];" % (i, i, i))
         if i in junction_steps:
             A("#pragma unroll")
             A("for (int r = 0; r < 9; r++) { TR[r] = (Lb == %d) ? Rc[r] : TR[r]; } // pose of the parent branch's frame in this branch's frame" % i)
@@ -448,6 +478,8 @@ def _emit_branch_inner(self, mode, use_thread_group=False):
     A("  for (int r = 0; r < 3; r++) { S[r] = (ax == 0) ? myR[3*r] : ((ax == 1) ? myR[3*r+1] : myR[3*r+2]); } }")
     A("S[3] = myp[1]*S[2] - myp[2]*S[1]; S[4] = myp[2]*S[0] - myp[0]*S[2]; S[5] = myp[0]*S[1] - myp[1]*S[0];")
     A("T I[10]; // this link's inertia about the origin of its branch frame")
+    if bfam:
+        A("T IB[10]; // ... and about pB")
     A("{", True)
     A("T d[3], RI[9];")
     A("#pragma unroll")
@@ -457,15 +489,25 @@ def _emit_branch_inner(self, mode, use_thread_group=False):
     A("RI[3*r+1] = myR[3*r]*Lc[1] + myR[3*r+1]*Lc[3] + myR[3*r+2]*Lc[4];")
     A("RI[3*r+2] = myR[3*r]*Lc[2] + myR[3*r+1]*Lc[4] + myR[3*r+2]*Lc[5];")
     self.gen_add_end_control_flow()
-    A("const T md0 = Lc[9]*d[0], md1 = Lc[9]*d[1], md2 = Lc[9]*d[2];")
-    for k, (r_, c_) in enumerate(((0, 0), (0, 1), (0, 2), (1, 1), (1, 2), (2, 2))):
-        rot = "RI[%d]*myR[%d] + RI[%d]*myR[%d] + RI[%d]*myR[%d]" % (3 * r_, 3 * c_, 3 * r_ + 1, 3 * c_ + 1, 3 * r_ + 2, 3 * c_ + 2)
-        if r_ == c_:
-            o1, o2 = [x for x in range(3) if x != r_]
-            A("I[%d] = %s + md%d*d[%d] + md%d*d[%d];" % (k, rot, o1, o1, o2, o2))
-        else:
-            A("I[%d] = %s - md%d*d[%d];" % (k, rot, r_, c_))
-    A("I[6] = md0; I[7] = md1; I[8] = md2; I[9] = Lc[9];")
+    A("T rot[6];")
+    pairs = ((0, 0), (0, 1), (0, 2), (1, 1), (1, 2), (2, 2))
+    for k, (r_, c_) in enumerate(pairs):
+        A("rot[%d] = RI[%d]*myR[%d] + RI[%d]*myR[%d] + RI[%d]*myR[%d];" % (k, 3 * r_, 3 * c_, 3 * r_ + 1, 3 * c_ + 1, 3 * r_ + 2, 3 * c_ + 2))
+
+    def parallel_axis(dst, dv):
+        A("{ const T md0 = Lc[9]*%s[0], md1 = Lc[9]*%s[1], md2 = Lc[9]*%s[2];" % (dv, dv, dv))
+        for k, (r_, c_) in enumerate(pairs):
+            if r_ == c_:
+                o1, o2 = [x for x in range(3) if x != r_]
+                A("  %s[%d] = rot[%d] + md%d*%s[%d] + md%d*%s[%d];" % (dst, k, k, o1, dv, o1, o2, dv, o2))
+            else:
+                A("  %s[%d] = rot[%d] - md%d*%s[%d];" % (dst, k, k, r_, dv, c_))
+        A("  %s[6] = md0; %s[7] = md1; %s[8] = md2; %s[9] = Lc[9]; }" % (dst, dst, dst, dst))
+
+    parallel_axis("I", "d")
+    if bfam:
+        A("T dB[3] = {d[0] - pB[0], d[1] - pB[1], d[2] - pB[2]}; // centre of mass relative to pB")
+        parallel_axis("IB", "dB")
     self.gen_add_end_control_flow()
     A("const T damping = Lc[10]; (void)damping;")
 
@@ -547,6 +589,11 @@ def _emit_branch_inner(self, mode, use_thread_group=False):
         A("#pragma unroll")
         A("for (int r = 0; r < 10; r++) { IC[r] = I[r]; }")
         A("grid_suffix_sum(IC, mkd);")
+        if bfam:
+            A("T ICB[10]; // composite about pB (leaf branches only: nothing is handed up into it)")
+            A("#pragma unroll")
+            A("for (int r = 0; r < 10; r++) { ICB[r] = IB[r]; }")
+            A("grid_suffix_sum(ICB, mkd);")
     else:
         A("(void)IC;")
     if use_B:
@@ -628,6 +675,9 @@ def _emit_branch_inner(self, mode, use_thread_group=False):
         A("T t1[6], t4[3];")
         A("grid_rbi_mul(t1, IC, S);")
         A("grid_btmul(t4, BC, S);")
+        if bfam:
+            for ln in _t1m_lines():
+                A(ln)
         A("if (active) { s_qdd[jid] = s_u[jid] - (grid_dot6(S, fC) + damping*qd); }")
         A("{", True)
         A("T t2[6]; grid_bmul(t2, BC, S); grid_rbi_mul_peq(t2, IC, Pd, static_cast<T>(2));")
@@ -639,7 +689,10 @@ def _emit_branch_inner(self, mode, use_thread_group=False):
             A("#pragma unroll")
             A("for (int r = 0; r < 6; r++) { vr[r] += Spi[r]*qdi; }")
             A("grid_mxm(Pdi, vr, Spi);")
-            A("const T mkj = grid_dot6(Spi, t1), up_d = grid_dot6(Spi, t2);")
+            if bfam:
+                A("const T mkj = %s, up_d = grid_dot6(Spi, t2);" % _MKJ_FAM)
+            else:
+                A("const T mkj = grid_dot6(Spi, t1), up_d = grid_dot6(Spi, t2);")
             A("const T lo_d = static_cast<T>(2)*grid_dot6(t1, Pdi) + t4[0]*Spi[0] + t4[1]*Spi[1] + t4[2]*Spi[2];")
             A("// (branch-free: lanes that have no such entry write to a spare word)")
             A("*(act%d ? &s_Mc[mstart + plen - %d] : s_trash) = mkj; // (ancestors in ascending order, then the diagonal)" % (i, i + 1))
@@ -649,6 +702,9 @@ def _emit_branch_inner(self, mode, use_thread_group=False):
         self.gen_add_end_control_flow()
     else:  # fd, minv: only the joint-space inertia, M[i][k] = S_i . (I^C_k S_k) for the ancestors-or-self i of this lane's joint k
         A("T t1[6]; grid_rbi_mul(t1, IC, S);")
+        if bfam:
+            for ln in _t1m_lines():
+                A(ln)
         if mode == "fd":
             A("if (active) { s_qdd[jid] = s_u[jid] - (grid_dot6(S, fC) + damping*qd); }")
         A("{", True)
@@ -662,7 +718,7 @@ def _emit_branch_inner(self, mode, use_thread_group=False):
             if i > 0:
                 A("  #pragma unroll")
                 A("  for (int r = 0; r < 6; r++) { Sn[r] = s_Sp[%d + r]; }" % (6 * (i - 1)))
-            A("  *(act%d ? &s_Mc[mstart + plen - %d] : s_trash) = grid_dot6(Spi, t1); // (ancestors in ascending order, then the diagonal)" % (i, i + 1))
+            A("  *(act%d ? &s_Mc[mstart + plen - %d] : s_trash) = %s; // (ancestors in ascending order, then the diagonal)" % (i, i + 1, _MKJ_FAM if bfam else "grid_dot6(Spi, t1)"))
             A("  GRID_SCHED_FENCE(); }")
         self.gen_add_end_control_flow()
     self.gen_add_sync(use_thread_group)
