@@ -32,6 +32,8 @@ live in LDS here, the tip-frame inner replicates a dense factorisation in regist
 """
 import numpy as np
 
+from ._tip_frame_gradient import _probe
+
 
 def gen_branch_frame_plan(self):
     """Decompose the tree into branches, pack them into DPP rows, derive the per-lane tables.  Returns None when the robot is out of scope."""
@@ -456,6 +458,7 @@ def _emit_branch_inner(self, mode, use_thread_group=False):
             A("GRID_SCHED_FENCE();")
         self.gen_add_end_control_flow()
     self.gen_add_end_control_flow()
+    _probe(self, "chain", "myR:9", "myp:3", "TR:9", "Tp:3", "gvec:3")
     self.gen_add_sync(use_thread_group)
     # ------------------------------------------------------------------ own link: S, inertia in F_b
     TS(2)
@@ -510,6 +513,9 @@ def _emit_branch_inner(self, mode, use_thread_group=False):
         parallel_axis("IB", "dB")
     self.gen_add_end_control_flow()
     A("const T damping = Lc[10]; (void)damping;")
+    _probe(self, "link", "S:6", "I:10")
+    if bfam:
+        _probe(self, "link", "IB:10")
 
     def walk_open(with_qdd):
         """Software-pipelined walk along the root path, root -> tip: the LDS reads of step i-1 are issued before the arithmetic of step i and
@@ -601,6 +607,10 @@ def _emit_branch_inner(self, mode, use_thread_group=False):
     if use_f:
         A("grid_suffix_sum(fC, mkd);")
     A("// (composites over the rest of the branch so far)")
+    if use_I:
+        _probe(self, "comp_scan", "IC:10")
+        if bfam:
+            _probe(self, "comp_scan", "ICB:10")
     for lv in range(maxlevel, 0, -1):
         A("{ // tree level %d -> %d: branch totals re-expressed in the parent branch's frame and handed to all of its lanes" % (lv, lv - 1), True)
         A("T y[28];")
@@ -610,6 +620,8 @@ def _emit_branch_inner(self, mode, use_thread_group=False):
             A("grid_coriolis_up(&y[10], TR, Tp, BC);")
         if use_f:
             A("grid_force_up(&y[22], TR, Tp, fC);")
+        if use_I:
+            _probe(self, "handover", "y:10")
         A("if (active && level == %d && pos == 0) {" % lv, True)
         for (u_, lo_, hi_) in ((use_I, 0, 10), (use_B, 10, 22), (use_f, 22, 28)):
             if u_:
@@ -668,6 +680,10 @@ def _emit_branch_inner(self, mode, use_thread_group=False):
         self.gen_add_end_control_flow()
         self.gen_add_end_function()
         return
+    if use_I:
+        _probe(self, "comp_I", "IC:10")
+    if use_B:
+        _probe(self, "comp_BF", "BC:12", "fC:6")
     # ------------------------------------------------------------------ pass 1
     TS(4)
     if mode == "fdgrad":
@@ -678,6 +694,8 @@ def _emit_branch_inner(self, mode, use_thread_group=False):
         if bfam:
             for ln in _t1m_lines():
                 A(ln)
+            _probe(self, "t1", "t1m:6")
+        _probe(self, "t1", "t1:6")
         A("if (active) { s_qdd[jid] = s_u[jid] - (grid_dot6(S, fC) + damping*qd); }")
         A("{", True)
         A("T t2[6]; grid_bmul(t2, BC, S); grid_rbi_mul_peq(t2, IC, Pd, static_cast<T>(2));")
@@ -695,7 +713,7 @@ def _emit_branch_inner(self, mode, use_thread_group=False):
                 A("const T mkj = grid_dot6(Spi, t1), up_d = grid_dot6(Spi, t2);")
             A("const T lo_d = static_cast<T>(2)*grid_dot6(t1, Pdi) + t4[0]*Spi[0] + t4[1]*Spi[1] + t4[2]*Spi[2];")
             A("// (branch-free: lanes that have no such entry write to a spare word)")
-            A("*(act%d ? &s_Mc[mstart + plen - %d] : s_trash) = mkj; // (ancestors in ascending order, then the diagonal)" % (i, i + 1))
+            A("*(act%d ? &s_Mc[mstart + plen - %d] : s_trash) = %s; // (ancestors in ascending order, then the diagonal)" % (i, i + 1, "static_cast<T>(static_cast<float>(mkj))" if "M" in tuple(self.tuning.get("round_probe", ())) else "mkj"))
             A("*(act%d ? &s_df_du[(%d + jid)*%d + pj%d] : s_trash) = up_d + ((own == %d) ? damping : Z); // + damping on the diagonal (oracle _test.py:486)" % (i, n, n, i, i))
             A("*((act%d && own != %d) ? &s_df_du[(%d + pj%d)*%d + jid] : s_trash) = lo_d;" % (i, i, n, i, n))
             walk_close()
@@ -747,9 +765,10 @@ def _emit_branch_inner(self, mode, use_thread_group=False):
             A("#pragma unroll")
             A("for (int i = 0; i < %d; i++) { bq[i] = s_qdd[cbase + i]; }" % Nc)
         for k in range(Nc - 1, -1, -1):
-            A("const T rd%d = grid_rcp(A%d_%d);" % (k, k, k))
+            R32 = (lambda e: "static_cast<T>(static_cast<float>(%s))" % e) if "factor" in tuple(self.tuning.get("round_probe", ())) else (lambda e: e)
+            A("const T rd%d = %s;" % (k, R32("grid_rcp(A%d_%d)" % (k, k))))
             if an[k]:
-                A(" ".join("const T U%d_%d = A%d_%d*rd%d;" % (i, k, i, k, k) for i in an[k]))
+                A(" ".join("const T U%d_%d = %s;" % (i, k, R32("A%d_%d*rd%d" % (i, k, k))) for i in an[k]))
                 for j in an[k]:
                     A(" ".join("A%d_%d -= U%d_%d*A%d_%d;" % (i, j, i, k, j, k) for i in an[k] if i <= j))
                 if with_rhs:
