@@ -27,6 +27,9 @@ TUNING_DEFAULTS = {
     "dpp_asm": True,            # lane-group scans as single v_fmac_f32_dpp instructions (inline asm) instead of builtin DPP move + FMA
     "tip_chain": "select",      # select | lds: how the tip-frame chain hands (R, p) to the owning lane
     "nt_store": True,           # non-temporal output stores
+    "stagger": 0,               # forward_dynamics_gradient kernel: waves in odd wave slots of their SIMD start k*64 cycles late (0 = off), so that the two
+                                # waves of a SIMD do not load, compute and store in lock-step
+    "fast_sincos": True,        # fp32 joint angles: branch-free Cody-Waite + minimax polynomials (29 instructions) instead of the math library's sincosf (120)
     "composite_scan": "f32",    # f32 | f64: precision of the suffix sums of the link inertias (tip/branch-frame paths); f64 = exact sums, rounded once
     "base_origin": "auto",      # auto | off | <joint position>: tip-frame path - the joint-space inertia entries of the base half of a chain are
                                 # evaluated about the origin of this joint instead of the tip (fp32 accuracy); auto = L // 2 for L >= 5

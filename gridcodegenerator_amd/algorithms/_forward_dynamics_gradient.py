@@ -136,6 +136,10 @@ def gen_forward_dynamics_gradient_kernel(self, use_thread_group=False, use_qdd_M
     self.gen_add_code_line("__global__ GRID_LAUNCH_BOUNDS")
     self.gen_add_code_line(func_def, True)
     self.gen_kernel_prologue("GRID_LDS_PER_SOLVE" if use_qdd_Minv_input else "FD_DU_LDS_PER_SOLVE")
+    if int(self.tuning["stagger"]) > 0 and not use_qdd_Minv_input and not single_call_timing:
+        self.gen_add_code_line("#if defined(__HIP_DEVICE_COMPILE__)")
+        self.gen_add_code_line("if (__builtin_amdgcn_s_getreg(4 | (0 << 6) | (3 << 11)) & 1) { __builtin_amdgcn_s_sleep(%d); } // HW_ID.wave_id: the second wave of a SIMD starts late" % min(127, int(self.tuning["stagger"])))
+        self.gen_add_code_line("#endif")
     if self.tuning["debug_stop"] == 9:  # timing ablation only: an empty kernel (launch + dispatch cost)
         self.gen_add_code_line("if (NUM_TIMESTEPS > -1) {return;}")
     if use_qdd_Minv_input:

@@ -187,7 +187,7 @@ def gen_load_update_XImats_helpers(self, use_thread_group=False):
         "// polynomials on [-pi/4, pi/4]: max error 1.2 ulp(1) for |x| <= 1e5 (checked against double precision on 10^7 points), 29 instructions and no",
         "// branch in the common case - the math library's sincosf is 120 instructions and three branches.  Larger arguments (and non-finite ones) take the library path.",
         "__device__ __forceinline__ void grid_sincos(const float x, float *s, float *c) {",
-        "    if (!(fabsf(x) <= 65536.0f)) { sincosf(x, s, c); return; }",
+        "    if (%s) { sincosf(x, s, c); return; }" % ("!(fabsf(x) <= 65536.0f)" if self.tuning["fast_sincos"] else "true"),
         "    const float k = rintf(x*0.6366197466850281f);",
         "    float r = fmaf(k, -1.5707963705062866f, x);        // pi/2 = hi + mid + lo",
         "    r = fmaf(k, 4.371138828673793e-08f, r);",

@@ -425,6 +425,84 @@ def test_fp32_error_tail_of_the_fast_paths_is_guarded(name, max_tol, p999_tol, t
         lib.close()
 
 
+def test_baseline_configs_at_their_full_sizes(torch_cuda, libs):
+    """BASELINE.json configs 2-4 at the batch sizes they name (config 1 is the headline test above, config 5 the second-order test below):
+    2: iiwa14 inverse_dynamics + inverse_dynamics_gradient, batch 1024 (every solve vs the oracle);
+    3: quadruped ABA forward dynamics + forward dynamics + gradient, batch 4096 (every solve of q-dd, a 512-solve subset of the gradient);
+    4: 30-DoF humanoid direct_minv + forward_dynamics_gradient, batch 16384 (random subsets)."""
+    from oracle.rbd_oracle import Oracle
+
+    torch = torch_cuda
+    st = torch.cuda.current_stream().cuda_stream
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).cuda()
+    E = lambda *shape: torch.full(shape, float("nan"), dtype=torch.float32, device="cuda")
+    # ---- config 2
+    robot = RobotModel.from_fixture("iiwa14")
+    lib, n, N = libs("iiwa14"), robot.n, 1024
+    x, qdd = _so_inputs(n, N, seed=41)
+    orc = Oracle(robot)
+    c, dc = E(N, n), E(N, 2 * n * n)
+    lib.inverse_dynamics_device(T(x), T(qdd), N, c, stream=st)
+    lib.inverse_dynamics_gradient_device(T(x), T(qdd), N, dc, stream=st)
+    torch.cuda.synchronize()
+    x64 = x.astype(np.float64)
+    assert per_solve_err(c.cpu().numpy(), orc.rnea_batch(x64, qdd.astype(np.float64))) <= TOL
+    assert per_solve_err(dc.cpu().numpy(), orc.rnea_grad_batch(x64, qdd.astype(np.float64))) <= TOL
+    # ---- config 3
+    robot = RobotModel.from_fixture("hyq")
+    lib, n, N = libs("hyq"), robot.n, 4096
+    x, _ = _so_inputs(n, N, seed=42)
+    orc = Oracle(robot)
+    a_aba, a_fd, df = E(N, n), E(N, n), E(N, 2 * n * n)
+    lib.aba_device(T(x), N, a_aba, stream=st)
+    lib.forward_dynamics_device(T(x), N, a_fd, stream=st)
+    lib.forward_dynamics_gradient_device(T(x), N, df, stream=st)
+    torch.cuda.synchronize()
+    x64 = x.astype(np.float64)
+    qdd_ref = np.stack([orc.fd_grad(x64[k, :n], x64[k, n:2 * n], x64[k, 2 * n:], full=True)[1] for k in range(N)])
+    assert per_solve_err(a_aba.cpu().numpy(), qdd_ref) <= TOL
+    assert per_solve_err(a_fd.cpu().numpy(), qdd_ref) <= TOL
+    idx = np.random.default_rng(3).choice(N, 512, replace=False)
+    ref, _ = orc.fd_grad_batch(x64[idx])
+    assert per_solve_err(df.cpu().numpy()[idx], ref) <= TOL
+    # ---- config 4
+    robot = RobotModel.from_fixture("atlas")
+    n, N = robot.n, 16384
+    lib = GridLibrary(build_library("atlas"), device=0, max_timesteps=N)
+    try:
+        x, _ = _so_inputs(n, N, seed=43)
+        orc = Oracle(robot)
+        Mi = E(N, n * n)
+        lib.direct_minv_device(T(x), N, Mi, stream=st)
+        torch.cuda.synchronize()
+        got = Mi.cpu().numpy()
+        assert np.isfinite(got).all()
+        idx = np.random.default_rng(4).choice(N, 128, replace=False)
+        ref = orc.minv_batch(x[idx, :n].astype(np.float64))   # device layout: column-major, upper triangle (zeros below the diagonal)
+        assert per_solve_err(got[idx], ref) <= TOL
+    finally:
+        lib.close()
+
+
+def test_single_process_multi_handle_driver_on_the_gpu(torch_cuda):
+    """SURVEY.md section 8(e) in one process: G handles (all on the one GPU of the test box, which is how the split is rehearsed without a
+    multi-GPU node), one host thread per handle, the batch cut into contiguous ranges - bit-identical to the one-handle result."""
+    from gridcodegenerator_amd.runtime import MultiGpuGrid
+
+    so = build_library("iiwa14")
+    single = GridLibrary(so, device=0, max_timesteps=16384)
+    x = inputs(7, 16384, seed=0)
+    ref = single.forward_dynamics_gradient_host(x)
+    for G in (2, 3, 8):
+        multi = MultiGpuGrid(so, devices=[0] * G, max_timesteps=16384)
+        try:
+            assert np.array_equal(multi.forward_dynamics_gradient_host(x), ref), G
+            assert np.array_equal(multi.forward_dynamics_gradient_host(x[:1001]), ref[:1001]), G  # ragged split
+        finally:
+            multi.close()
+    single.close()
+
+
 def _so_inputs(n, N, seed):
     rng = np.random.default_rng(seed)
     x = np.hstack([rng.uniform(-np.pi, np.pi, (N, n)), rng.uniform(-2, 2, (N, n)), rng.uniform(-10, 10, (N, n))]).astype(np.float32)
