@@ -38,6 +38,7 @@ TUNING_ABLATION = {
     "debug_stop": 0,            # truncate the kernel after a phase / cycle stamps (tools/prof_ablation.sh, tools/phase_stamps.py)
     "no_pins": False,           # drop the register pins
     "no_wave_barrier": False,   # drop the wave barrier of grid_wave_sync (fences only)
+    "no_store": False,          # skip the final global store of every kernel (how much of a launch is the output leaving the chip?)
     "round_probe": (),          # accuracy diagnosis (tools/precision_probe.py): stages of the tip-frame inner whose results are rounded to fp32
                                 # inside the T = double instantiation - shows which stage's fp32 rounding the final error comes from
 }

@@ -606,12 +606,59 @@ int grid_forward_dynamics_gradient_multi_host(grid_handle **handles, int num_han
     GRID_GUARDED(return fd_grad_multi_host<float>(handles, num_handles, h_q_qd_u, num_timesteps, gravity, h_df_du);)
 }
 
-// ---- double (the hot path and its host form; T = double instantiations of the same generated kernels)
+// ---- double: the T = double instantiations of the same generated kernels (buffers allocated by the first *_f64 call)
 int grid_forward_dynamics_gradient_device_f64(grid_handle *h, const double *d_q_qd_u, int stride_q_qd_u, int num_timesteps, double gravity, double *d_df_du, void *stream) {
     GRID_GUARDED(return fd_grad_device<double>(h, d_q_qd_u, stride_q_qd_u, num_timesteps, gravity, d_df_du, stream);)
 }
+int grid_forward_dynamics_gradient_qdd_minv_device_f64(grid_handle *h, const double *d_q_qd, int stride_q_qd, const double *d_qdd, const double *d_Minv,
+                                                       int num_timesteps, double gravity, double *d_df_du, void *stream) {
+    GRID_GUARDED(return fd_grad_qdd_minv_device<double>(h, d_q_qd, stride_q_qd, d_qdd, d_Minv, num_timesteps, gravity, d_df_du, stream);)
+}
+int grid_inverse_dynamics_device_f64(grid_handle *h, const double *d_q_qd, int stride_q_qd, const double *d_qdd, int num_timesteps, double gravity, double *d_c, void *stream) {
+    GRID_GUARDED(return id_device<double>(h, d_q_qd, stride_q_qd, d_qdd, num_timesteps, gravity, d_c, stream);)
+}
+int grid_inverse_dynamics_gradient_device_f64(grid_handle *h, const double *d_q_qd, int stride_q_qd, const double *d_qdd, int num_timesteps, double gravity,
+                                              double *d_dc_du, void *stream) {
+    GRID_GUARDED(return id_grad_device<double>(h, d_q_qd, stride_q_qd, d_qdd, num_timesteps, gravity, d_dc_du, stream);)
+}
+int grid_direct_minv_device_f64(grid_handle *h, const double *d_q, int stride_q, int num_timesteps, double *d_Minv, void *stream) {
+    GRID_GUARDED(return minv_device<double>(h, d_q, stride_q, num_timesteps, d_Minv, stream);)
+}
+int grid_forward_dynamics_device_f64(grid_handle *h, const double *d_q_qd_u, int stride_q_qd_u, int num_timesteps, double gravity, double *d_qdd, void *stream) {
+    GRID_GUARDED(return fd_device<double>(h, d_q_qd_u, stride_q_qd_u, num_timesteps, gravity, d_qdd, stream, false);)
+}
+int grid_aba_device_f64(grid_handle *h, const double *d_q_qd_tau, int stride_q_qd, int num_timesteps, double gravity, double *d_qdd, void *stream) {
+    GRID_GUARDED(return fd_device<double>(h, d_q_qd_tau, stride_q_qd, num_timesteps, gravity, d_qdd, stream, true);)
+}
+int grid_idsva_so_device_f64(grid_handle *h, const double *d_q_qd_u, int stride_q_qd_u, const double *d_qdd, int num_timesteps, double gravity, double *d_idsva_so, void *stream) {
+    GRID_GUARDED(return idsva_so_device<double>(h, d_q_qd_u, stride_q_qd_u, d_qdd, num_timesteps, gravity, d_idsva_so, stream);)
+}
+int grid_fdsva_so_device_f64(grid_handle *h, const double *d_q_qd_u, int stride_q_qd_u, int num_timesteps, double gravity, double *d_df2, void *stream) {
+    GRID_GUARDED(return fdsva_so_device<double>(h, d_q_qd_u, stride_q_qd_u, num_timesteps, gravity, d_df2, stream);)
+}
 int grid_forward_dynamics_gradient_host_f64(grid_handle *h, const double *h_q_qd_u, int num_timesteps, double gravity, double *h_df_du) {
     GRID_GUARDED(return fd_grad_host<double>(h, h_q_qd_u, num_timesteps, gravity, h_df_du);)
+}
+int grid_inverse_dynamics_host_f64(grid_handle *h, const double *h_q_qd, int stride_q_qd, const double *h_qdd, int num_timesteps, double gravity, double *h_c) {
+    GRID_GUARDED(return id_host<double>(h, h_q_qd, stride_q_qd, h_qdd, num_timesteps, gravity, h_c, 0);)
+}
+int grid_inverse_dynamics_gradient_host_f64(grid_handle *h, const double *h_q_qd, int stride_q_qd, const double *h_qdd, int num_timesteps, double gravity, double *h_dc_du) {
+    GRID_GUARDED(return id_host<double>(h, h_q_qd, stride_q_qd, h_qdd, num_timesteps, gravity, h_dc_du, 1);)
+}
+int grid_direct_minv_host_f64(grid_handle *h, const double *h_q, int stride_q, int num_timesteps, double *h_Minv) {
+    GRID_GUARDED(return minv_host<double>(h, h_q, stride_q, num_timesteps, h_Minv);)
+}
+int grid_forward_dynamics_host_f64(grid_handle *h, const double *h_q_qd_u, int num_timesteps, double gravity, double *h_qdd) {
+    GRID_GUARDED(return fd_host<double>(h, h_q_qd_u, num_timesteps, gravity, h_qdd, false);)
+}
+int grid_aba_host_f64(grid_handle *h, const double *h_q_qd_tau, int num_timesteps, double gravity, double *h_qdd) {
+    GRID_GUARDED(return fd_host<double>(h, h_q_qd_tau, num_timesteps, gravity, h_qdd, true);)
+}
+int grid_idsva_so_host_f64(grid_handle *h, const double *h_q_qd_u, const double *h_qdd, int num_timesteps, double gravity, double *h_idsva_so) {
+    GRID_GUARDED(return so_host<double>(h, h_q_qd_u, h_qdd, num_timesteps, gravity, h_idsva_so, 0);)
+}
+int grid_fdsva_so_host_f64(grid_handle *h, const double *h_q_qd_u, int num_timesteps, double gravity, double *h_df2) {
+    GRID_GUARDED(return so_host<double>(h, h_q_qd_u, nullptr, num_timesteps, gravity, h_df2, 1);)
 }
 
 int grid_forward_dynamics_gradient_single_timing(grid_handle *h, const float *h_q_qd_u, int reps, float gravity, float *h_df_du, double *us_per_call) {

@@ -245,7 +245,7 @@ def gen_kernel_save_result(self, store_to_name, stride, amount, use_thread_group
                              "T *dst = &d_" + store_to_name + "[static_cast<size_t>(k - grp + gw0)*" + str(amount) + "];",
                              "const int wl = tid & 63;",
                              "int wn = gpb*GRID_LANES_PER_SOLVE - (tid & ~63); wn = wn < 64 ? wn : 64; // lanes of this wave that take part (the last wave of a block may be partial)",
-                             "for (int e = 4*wl; e + 3 < total; e += 4*wn) { T tmp[4]; __builtin_memcpy(tmp, __builtin_assume_aligned(src + e, 4*sizeof(T) < 16 ? 4*sizeof(T) : 16), 4*sizeof(T)); grid_store4(dst + e, tmp); }",
+                             ("if (NUM_TIMESTEPS_OUT < 0) " if self.tuning["no_store"] else "") + "for (int e = 4*wl; e + 3 < total; e += 4*wn) { T tmp[4]; __builtin_memcpy(tmp, __builtin_assume_aligned(src + e, 4*sizeof(T) < 16 ? 4*sizeof(T) : 16), 4*sizeof(T)); grid_store4(dst + e, tmp); }",
                              "{ const int e = (total & ~3) + wl; if (wl < 3 && e < total) { dst[e] = src[e]; } }"])
     self.gen_add_end_control_flow()
     self.gen_add_sync(use_thread_group)

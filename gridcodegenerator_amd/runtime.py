@@ -153,6 +153,32 @@ class GridLibrary:
                                                                      ctypes.c_void_p(out.ctypes.data)))
         return out
 
+    def host_f64(self, algorithm, *arrays, gravity=9.81):
+        """T = double host-buffer entry points: algorithm in {inverse_dynamics, inverse_dynamics_gradient, direct_minv, forward_dynamics, aba,
+        idsva_so, fdsva_so}; arrays as for the float methods (q_qd[, qdd] / q / q_qd_u[, qdd]) in float64."""
+        n = self.n
+        D = lambda a: None if a is None else np.ascontiguousarray(a, dtype=np.float64)
+        P = lambda a: ctypes.c_void_p(None) if a is None else ctypes.c_void_p(a.ctypes.data)
+        a0 = D(arrays[0])
+        N = a0.shape[0]
+        cols = {"inverse_dynamics": n, "inverse_dynamics_gradient": 2 * n * n, "direct_minv": n * n, "forward_dynamics": n, "aba": n,
+                "idsva_so": 4 * n ** 3, "fdsva_so": 4 * n ** 3}[algorithm]
+        out = np.empty((N, cols), dtype=np.float64)
+        fn = getattr(self.lib, "grid_%s_host_f64" % algorithm)
+        g = ctypes.c_double(gravity)
+        if algorithm in ("inverse_dynamics", "inverse_dynamics_gradient"):
+            qdd = D(arrays[1]) if len(arrays) > 1 else None
+            rc = fn(self.handle, P(a0), ctypes.c_int(a0.shape[1]), P(qdd), ctypes.c_int(N), g, P(out))
+        elif algorithm == "direct_minv":
+            rc = fn(self.handle, P(a0), ctypes.c_int(a0.shape[1]), ctypes.c_int(N), P(out))
+        elif algorithm == "idsva_so":
+            qdd = D(arrays[1]) if len(arrays) > 1 else None
+            rc = fn(self.handle, P(a0), P(qdd), ctypes.c_int(N), g, P(out))
+        else:
+            rc = fn(self.handle, P(a0), ctypes.c_int(N), g, P(out))
+        self._check(rc)
+        return out
+
     def forward_dynamics_gradient_qdd_minv_host(self, q_qd, qdd, Minv, gravity=9.81):
         n = self.n
         x = self._host_in(q_qd, (2 * n, 3 * n), "q_qd")

@@ -10,7 +10,7 @@
  *   - every function returns 0 on success or a non-zero hipError_t value; grid_last_error() gives the text (per calling thread).
  *     No entry point ever exit()s or aborts the host process: the reference's host API prints "GPUassert: ..." and exit()s
  *     (reference GRiDCodeGenerator.py:279-286); the shim re-binds the generated header's error hook (GRID_ON_GPU_ERROR) instead;
- *   - T is float ("Suggested Type T is float", reference GRiDCodeGenerator.py:378); the hot path also has *_f64 entry points
+ *   - T is float ("Suggested Type T is float", reference GRiDCodeGenerator.py:378); every entry point also exists as *_f64
  *     (the T = double instantiation of the same generated kernels; its buffers are allocated by the first *_f64 call);
  *   - layouts (reference algorithms/_forward_dynamics_gradient.py:50,61,168 and SURVEY.md section 8(a) a1):
  *       q_qd_u [k*stride + {0..n | n..2n | 2n..3n}]            inputs, array-of-structs over the batch index k
@@ -107,10 +107,31 @@ int grid_forward_dynamics_gradient_qdd_minv_host(grid_handle *h, const float *h_
  * (reference helpers/_code_generation_helpers.py:46-47, the kernels' only cross-k structure is the grid-stride loop).  Synchronous. */
 int grid_forward_dynamics_gradient_multi_host(grid_handle **handles, int num_handles, const float *h_q_qd_u, int num_timesteps, float gravity, float *h_df_du);
 
-/* T = double instantiation of the hot path (reference: template <typename T> on every emitted function, GRiDCodeGenerator.py:312-380) */
+/* T = double instantiations (reference: template <typename T> on every emitted function, GRiDCodeGenerator.py:312-380): the same entry points with
+ * double buffers and a double gravity; their device and pinned host buffers are allocated by the first *_f64 call on a handle.  A block never asks
+ * for more LDS than a CU has: where the float block size does not fit in double precision the library launches fewer solves per block. */
 int grid_forward_dynamics_gradient_device_f64(grid_handle *h, const double *d_q_qd_u, int stride_q_qd_u, int num_timesteps, double gravity,
                                               double *d_df_du, void *stream);
+int grid_forward_dynamics_gradient_qdd_minv_device_f64(grid_handle *h, const double *d_q_qd, int stride_q_qd, const double *d_qdd, const double *d_Minv,
+                                                       int num_timesteps, double gravity, double *d_df_du, void *stream);
+int grid_inverse_dynamics_device_f64(grid_handle *h, const double *d_q_qd, int stride_q_qd, const double *d_qdd, int num_timesteps, double gravity,
+                                     double *d_c, void *stream);
+int grid_inverse_dynamics_gradient_device_f64(grid_handle *h, const double *d_q_qd, int stride_q_qd, const double *d_qdd, int num_timesteps, double gravity,
+                                              double *d_dc_du, void *stream);
+int grid_direct_minv_device_f64(grid_handle *h, const double *d_q, int stride_q, int num_timesteps, double *d_Minv, void *stream);
+int grid_forward_dynamics_device_f64(grid_handle *h, const double *d_q_qd_u, int stride_q_qd_u, int num_timesteps, double gravity, double *d_qdd, void *stream);
+int grid_aba_device_f64(grid_handle *h, const double *d_q_qd_tau, int stride_q_qd, int num_timesteps, double gravity, double *d_qdd, void *stream);
+int grid_idsva_so_device_f64(grid_handle *h, const double *d_q_qd_u, int stride_q_qd_u, const double *d_qdd, int num_timesteps, double gravity,
+                             double *d_idsva_so, void *stream);
+int grid_fdsva_so_device_f64(grid_handle *h, const double *d_q_qd_u, int stride_q_qd_u, int num_timesteps, double gravity, double *d_df2, void *stream);
 int grid_forward_dynamics_gradient_host_f64(grid_handle *h, const double *h_q_qd_u, int num_timesteps, double gravity, double *h_df_du);
+int grid_inverse_dynamics_host_f64(grid_handle *h, const double *h_q_qd, int stride_q_qd, const double *h_qdd, int num_timesteps, double gravity, double *h_c);
+int grid_inverse_dynamics_gradient_host_f64(grid_handle *h, const double *h_q_qd, int stride_q_qd, const double *h_qdd, int num_timesteps, double gravity, double *h_dc_du);
+int grid_direct_minv_host_f64(grid_handle *h, const double *h_q, int stride_q, int num_timesteps, double *h_Minv);
+int grid_forward_dynamics_host_f64(grid_handle *h, const double *h_q_qd_u, int num_timesteps, double gravity, double *h_qdd);
+int grid_aba_host_f64(grid_handle *h, const double *h_q_qd_tau, int num_timesteps, double gravity, double *h_qdd);
+int grid_idsva_so_host_f64(grid_handle *h, const double *h_q_qd_u, const double *h_qdd, int num_timesteps, double gravity, double *h_idsva_so);
+int grid_fdsva_so_host_f64(grid_handle *h, const double *h_q_qd_u, int num_timesteps, double gravity, double *h_df2);
 
 /* in-kernel timing probe: replaces forward_dynamics_gradient_single_timing<T> (reference :236-248); returns microseconds per solve */
 int grid_forward_dynamics_gradient_single_timing(grid_handle *h, const float *h_q_qd_u, int reps, float gravity, float *h_df_du, double *us_per_call);

@@ -112,12 +112,13 @@ extern "C" inline __attribute__((visibility("default"), used)) int hipemu_get_de
 #define __builtin_amdgcn_rcpf(x) (1.0f / (x))
 // cross-lane shuffle inside groups of `width` consecutive threads (width-aligned): exchange through a scratch array
 namespace hipemu {
-inline float g_shfl[1024];
-inline float shfl(float v, int src, int width) {
+template <typename V> inline V g_shfl[1024];  // (one exchange buffer per value type: the double instantiations shuffle doubles)
+template <typename V>
+inline V shfl(V v, int src, int width) {
     const unsigned t = threadIdx.x + threadIdx.y * blockDim.x;
-    g_shfl[t] = v;
+    g_shfl<V>[t] = v;
     wave_barrier();
-    const float r = g_shfl[(t & ~(unsigned)(width - 1)) + (unsigned)src];
+    const V r = g_shfl<V>[(t & ~(unsigned)(width - 1)) + (unsigned)src];
     wave_barrier();
     return r;
 }

@@ -87,15 +87,23 @@ def test_host_entry_points_of_every_algorithm(name, golden):
         assert np.isfinite(lib.fdsva_so_host(x3[:2])).all()
 
 
-def test_double_precision_entry_points_match_the_fp64_oracle(golden):
-    g = golden("iiwa14")
-    lib = emu_library("iiwa14", max_timesteps=16)
+@pytest.mark.parametrize("name", ["iiwa14", "tree12"])
+def test_double_precision_entry_points_match_the_fp64_goldens(name, golden):
+    """Every algorithm through its *_f64 host entry point against the goldens of the reference's own oracle, to rounding level: pins the generated
+    algorithms (tip-frame path for the arm, branch-frame path for the 12-DoF tree) independently of fp32 effects."""
+    g = golden(name)
+    lib = emu_library(name, max_timesteps=16)
     lib.set_launch_dims(0, 64)
-    N = 4
+    n, N = lib.n, 4
     x = np.hstack([g["q"], g["qd"], g["u"]])[:N].astype(np.float64)
+    col = lambda key: np.stack([g[key][k].T.reshape(-1) for k in range(N)])
     out = lib.forward_dynamics_gradient_host_f64(x)
-    ref = np.stack([g["df_du"][k].T.reshape(-1) for k in range(N)])
-    assert out.dtype == np.float64 and per_solve_err(out, ref) <= 1e-9
+    assert out.dtype == np.float64 and per_solve_err(out, col("df_du")) <= 1e-9
+    assert per_solve_err(lib.host_f64("inverse_dynamics", x[:, :2 * n], g["qdd"][:N]), g["c2"][:N]) <= 1e-9
+    assert per_solve_err(lib.host_f64("inverse_dynamics_gradient", x[:, :2 * n], g["qdd"][:N]), col("dc_du")) <= 1e-9
+    assert per_solve_err(lib.host_f64("direct_minv", x[:, :n]), col("Minv_upper")) <= 1e-9
+    assert per_solve_err(lib.host_f64("forward_dynamics", x), g["qdd"][:N]) <= 1e-9
+    assert per_solve_err(lib.host_f64("aba", x), g["qdd"][:N]) <= 1e-9
 
 
 @pytest.mark.parametrize("G,N", [(2, 16), (3, 13), (4, 3)])

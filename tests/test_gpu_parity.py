@@ -484,6 +484,35 @@ def test_baseline_configs_at_their_full_sizes(torch_cuda, libs):
         lib.close()
 
 
+@pytest.mark.parametrize("name", ["iiwa14", "hyq", "atlas"])
+def test_double_precision_c_abi_on_the_gpu(name, torch_cuda, golden):
+    """The *_f64 entry points (T = double instantiations of the same generated kernels) against the goldens of the reference's oracle to rounding
+    level, on the hardware: tip-frame path (arm, quadruped) and branch-frame path (humanoid: the library must launch fewer solves per block in double
+    precision so that a block fits the LDS of a CU)."""
+    g = golden(name)
+    lib = GridLibrary(build_library(name), device=0, max_timesteps=64)
+    try:
+        n, N = lib.n, g["q"].shape[0]
+        x = np.hstack([g["q"], g["qd"], g["u"]]).astype(np.float64)
+        col = lambda key: np.stack([g[key][k].T.reshape(-1) for k in range(N)])
+        assert per_solve_err(lib.forward_dynamics_gradient_host_f64(x), col("df_du")) <= 1e-9
+        torch = torch_cuda
+        d_in = torch.from_numpy(x).cuda()
+        d_out = torch.full((N, 2 * n * n), float("nan"), dtype=torch.float64, device="cuda")
+        lib.forward_dynamics_gradient_device_f64(d_in, N, d_out, stream=torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        assert per_solve_err(d_out.cpu().numpy(), col("df_du")) <= 1e-9
+        assert per_solve_err(lib.host_f64("inverse_dynamics", x[:, :2 * n], g["qdd"]), g["c2"]) <= 1e-9
+        assert per_solve_err(lib.host_f64("inverse_dynamics_gradient", x[:, :2 * n], g["qdd"]), col("dc_du")) <= 1e-9
+        assert per_solve_err(lib.host_f64("direct_minv", x[:, :n]), col("Minv_upper")) <= 1e-9
+        assert per_solve_err(lib.host_f64("forward_dynamics", x), g["qdd"]) <= 1e-9
+        assert per_solve_err(lib.host_f64("aba", x), g["qdd"]) <= 1e-9
+        out32 = lib.forward_dynamics_gradient_host(x.astype(np.float32))  # float and double state of one handle side by side
+        assert per_solve_err(out32, col("df_du")) <= TOL
+    finally:
+        lib.close()
+
+
 def test_single_process_multi_handle_driver_on_the_gpu(torch_cuda):
     """SURVEY.md section 8(e) in one process: G handles (all on the one GPU of the test box, which is how the split is rehearsed without a
     multi-GPU node), one host thread per handle, the batch cut into contiguous ranges - bit-identical to the one-handle result."""
