@@ -23,7 +23,8 @@ TUNING_DEFAULTS = {
     "fuse_fd": True,            # fused M^-1 || RNEA sweep of the column-walk forward dynamics (robots with <= 9 joints)
     "reuse_rnea": False,        # column walk re-uses v, I v, fx(v) I v of the RNEA(qdd=0) pass (measured slower: 16.6 vs 15.0 us)
     "min_waves": 0,             # second __launch_bounds__ argument (minimum waves per SIMD); 0 = compiler's choice
-    "so_unroll": None,          # inner-loop unrolling of idsva_so (None = full)
+    "so_unroll": None,          # inner-loop unrolling of idsva_so (None = full; subtree mapping only)
+    "so_mapping": "balanced",   # balanced | subtree: work distribution of the idsva_so main loops (algorithms/_idsva_so.py: gen_idsva_so_items)
     "dpp_asm": True,            # lane-group scans as single v_fmac_f32_dpp instructions (inline asm) instead of builtin DPP move + FMA
     "tip_chain": "select",      # select | lds: how the tip-frame chain hands (R, p) to the owning lane
     "nt_store": True,           # non-temporal output stores
@@ -87,7 +88,7 @@ class GRiDCodeGenerator:
         gen_forward_dynamics_inner_function_call, gen_forward_dynamics_inner, gen_forward_dynamics_device, gen_forward_dynamics_kernel, \
         gen_forward_dynamics_host, gen_forward_dynamics, \
         gen_aba_inner_temp_mem_size, gen_aba_inner_function_call, gen_aba_inner, gen_aba_device, gen_aba_kernel, gen_aba_host, gen_aba, \
-        gen_idsva_so_available, gen_idsva_so_mode, gen_idsva_so_rec, gen_idsva_so_tree_tables, gen_idsva_so_lds_layout, gen_idsva_so_inner_temp_mem_size, gen_idsva_so_inner_function_call, gen_idsva_so_inner, gen_idsva_so_device, gen_idsva_so_kernel, gen_idsva_so_host, gen_idsva_so, \
+        gen_idsva_so_available, gen_idsva_so_mode, gen_idsva_so_rec, gen_idsva_so_tree_tables, gen_idsva_so_items, gen_idsva_so_items_table, gen_idsva_so_lds_layout, gen_idsva_so_inner_temp_mem_size, gen_idsva_so_inner_function_call, gen_idsva_so_inner, gen_idsva_so_device, gen_idsva_so_kernel, gen_idsva_so_host, gen_idsva_so, \
         gen_fdsva_so_inner_temp_mem_size, gen_fdsva_so_stage_size, gen_fdsva_so_inner, gen_fdsva_so_device, gen_fdsva_so_kernel, gen_fdsva_so_host, gen_fdsva_so, \
         gen_inverse_dynamics_gradient_inner_temp_mem_size, gen_inverse_dynamics_gradient_kernel_max_temp_mem_size, \
         gen_inverse_dynamics_gradient_inner_function_call, gen_inverse_dynamics_gradient_inner, gen_dc_du_to_lds, gen_gradient_slots, gen_gradient_outputs_decl, \
@@ -273,7 +274,17 @@ class GRiDCodeGenerator:
                                      "const int IDSVA_SO_MAX_SOLVES_PER_BLOCK = IDSVA_SO_SUGGESTED_THREADS/GRID_LANES_PER_SOLVE; // lane groups of larger blocks retire",
                                      "const int IDSVA_SO_DYNAMIC_SHARED_MEM_COUNT = IDSVA_SO_MAX_SOLVES_PER_BLOCK*(IDSVA_SO_LDS_PER_SOLVE + IDSVA_SO_STAGE_PER_SOLVE);"])
             st_ = self.gen_fdsva_so_stage_size()
-            self.gen_add_code_lines(["const int FDSVA_SO_SUGGESTED_THREADS = 64; // fdsva_so keeps the 4 n^3 idsva_so tensors of every solve in LDS: fewer solves per block",
+            # block size of fdsva_so: the number of lane groups per block that lets the most solves be resident on a CU (its LDS holds the workspace,
+            # df/du and the 4 n^3 idsva_so tensors of every solve); ties go to the smaller block = more waves (measured on the 7-DoF arm, 65 536
+            # solves: 64 threads 707 us, 48: 652, 32: 606, 24: 596)
+            per = (lds["TOTAL"] + st_) * 4
+            best_g, best_res = 1, 0
+            for g_ in range(max(1, -(-24 // G)), max(1, 64 // G) + 1):  # (at least 24 lanes of a wave in use)
+                res = (155 * 1024 // (g_ * per)) * g_
+                if res > best_res:
+                    best_g, best_res = g_, res
+            fd_so_threads = best_g * G
+            self.gen_add_code_lines(["const int FDSVA_SO_SUGGESTED_THREADS = %d; // fdsva_so keeps the 4 n^3 idsva_so tensors of every solve in LDS: fewer solves per block" % fd_so_threads,
                                      "const int FDSVA_SO_STAGE_PER_SOLVE = " + str(st_) + "; // df/du (2 n^2, padded) + idsva_so (4 n^3), behind the block's slices",
                                      "const int FDSVA_SO_MAX_SOLVES_PER_BLOCK = FDSVA_SO_SUGGESTED_THREADS/GRID_LANES_PER_SOLVE;",
                                      "const int FDSVA_SO_DYNAMIC_SHARED_MEM_COUNT = FDSVA_SO_MAX_SOLVES_PER_BLOCK*(GRID_LDS_PER_SOLVE + FDSVA_SO_STAGE_PER_SOLVE);"])

@@ -106,6 +106,106 @@ def gen_idsva_so_inner(self, use_thread_group=False, use_qdd_input=False):
     return gen_idsva_so_inner_chain(self, use_thread_group)
 
 
+def gen_idsva_so_items(self):
+    """Balanced work distribution of the main loops (tuning so_mapping = balanced).  The reference's triples (joint j, ancestor-or-self an, subtree
+    member c) are grouped into ITEMS (c, m), m an ancestor-or-self of c: item (c, m) applies the operators of joint c to the vectors of joint m once
+    and then covers the triples (j = l, an = m, c) for every l on the path m .. c and (j = m, an = l, c) for every ancestor-or-self l of m.  With
+    lane <-> c (the subtree mapping) lane c executes all n^2 (m, l) combinations although only those with m, l <= c concern it: 43 % useful on a
+    7-joint chain.  Here every lane gets the same number of items (sorted by their trip counts so that the lanes of a slot run loops of similar
+    length) and fetches joint c's composites from lane c with cross-lane shuffles.  Returns (items[lane][slot] = (c, m) or None, slots,
+    max path trips per slot, max ancestor trips per slot)."""
+    m_ = self.model
+    n, G = m_.n, self.lanes_per_solve
+    depth = m_.depth
+    items = []
+    for c in range(n):
+        for a in sorted(m_.ancestors[c]) + [c]:
+            items.append((c, a, depth[c] - depth[a] + 1, depth[a] + 1))
+    slots = (len(items) + G - 1) // G
+    best = None
+    # all lanes of a slot run the path loop and the ancestor loop to the slot's longest trip counts: try a few orderings, keep the cheapest packing
+    for key in (lambda it: (-(it[2] + it[3]), -it[2]), lambda it: (-it[2], -it[3]), lambda it: (-it[3], -it[2]), lambda it: (-(it[2] + it[3]), -it[3])):
+        order = sorted(items, key=lambda it: key(it) + (it[0], it[1]))
+        table = [[None] * slots for _ in range(G)]
+        tA, tB = [0] * slots, [0] * slots
+        for i, it in enumerate(order):
+            sl, ln = divmod(i, G)
+            table[ln][sl] = (it[0], it[1])
+            tA[sl] = max(tA[sl], it[2])
+            tB[sl] = max(tB[sl], it[3])
+        cost = sum(450 + 130 * a + 200 * b for a, b in zip(tA, tB))
+        if best is None or cost < best[0]:
+            best = (cost, table, tA, tB)
+    _, table, tA, tB = best
+    return table, slots, tA, tB
+
+
+def gen_idsva_so_items_table(self):
+    """The items of gen_idsva_so_items as a flat int table [lane][slot][c, m] (-1, -1 = no item), emitted at namespace scope with the model constants
+    (a function-local static would be shared between the robot libraries of one process by the host toolchain of the test emulation)."""
+    table, slots, _, _ = self.gen_idsva_so_items()
+    flat = []
+    for ln in range(self.lanes_per_solve):
+        for sl in range(slots):
+            flat += list(table[ln][sl]) if table[ln][sl] is not None else [-1, -1]
+    return flat
+
+
+def _so_emit_balanced_main(self, tree):
+    """Main loops in the balanced mapping (see gen_idsva_so_items); expects the per-lane quantities of _SO_PREP (lane <-> joint) and the records in s_X."""
+    n, G = self.model.n, self.lanes_per_solve
+    table, slots, tA, tB = self.gen_idsva_so_items()
+    A = self.gen_add_code_line
+    A("// balanced mapping: this lane's items (c, m), %d per lane, from the table grid_so_items (emitted with the model constants)" % slots)
+    A("const bool own_lane = active@NOSTORE@;".replace("@NOSTORE@", " && (gravity < static_cast<T>(-1e30))" if self.tuning["debug_stop"] == 30 else ""))
+    A("const T (&oIC)[10] = IC; const T (&oBC)[12] = BC; const T (&oT1)[6] = T1; const T (&oT2)[3] = T2; const T (&oT3)[6] = T3; const T (&oT4)[6] = T4;")
+    A("const T (&oICPd)[6] = ICPd; const T (&oS)[6] = S; const T (&oPd)[6] = Pd;")
+    par = (lambda l: "static_cast<int>(s_X[20*%s + 18])" % l) if tree else (lambda l: "(%s - 1)" % l)
+    for sl in range(slots):
+        A("{ // item slot %d: path loops of up to %d steps, ancestor loops of up to %d steps" % (sl, tA[sl], tB[sl]), True)
+        A("const int ic = grid_so_items[%d*lane + %d], im = grid_so_items[%d*lane + %d];" % (2 * slots, 2 * sl, 2 * slots, 2 * sl + 1))
+        A("const bool item = ic >= 0; const int c = item ? ic : 0, m = item ? im : 0; const bool own = own_lane && item;")
+        A("T IC[10], BC[12], T1[6], T2[3], T3[6], T4[6], ICPd[6], S[6], Pd[6]; // joint c's quantities, fetched from its lane")
+        for nm, ln_ in (("IC", 10), ("BC", 12), ("T1", 6), ("T2", 3), ("T3", 6), ("T4", 6), ("ICPd", 6), ("S", 6), ("Pd", 6)):
+            A("#pragma unroll")
+            A("for (int r = 0; r < %d; r++) { %s[r] = __shfl(o%s[r], c, GRID_LANES_PER_SOLVE); }" % (ln_, nm, nm))
+        _so_emit(self, _SO_OPERATORS)
+        def fetch(dst_s, dst_p, dst_par, lv, decl):
+            A("%s#pragma unroll" % "")
+            A("for (int r = 0; r < 6; r++) { %s[r] = s_X[20*%s + r]; %s[r] = s_X[20*%s + 6 + r]; }" % (dst_s, lv, dst_p, lv))
+            A("%s%s = %s;" % ("const int " if decl else "", dst_par, ("static_cast<int>(s_X[20*%s + 18])" % lv) if tree else ("%s - 1" % lv)))
+
+        for (title, start, tmax, more_expr, bodies) in (
+                ("joint j = l walks the path c -> m, ancestor-or-self an = m", "c", tA[sl], "va && (l != m)", "A"),
+                ("joint j = m, ancestor-or-self an = l walks m -> root", "m", tB[sl], "va && (lpar >= 0)", "BC")):
+            A("{ // %s; the record of the next joint is fetched while this one is worked on" % title, True)
+            A("int l = %s, lpar; bool va = true;" % start)
+            A("T xS[6], xP[6];")
+            fetch("xS", "xP", "lpar", "l", False)
+            A("#pragma unroll 1")
+            A("for (int t = 0; t < %d; t++) {" % tmax, True)
+            A("const bool more = %s; const int ln = more ? lpar : l;" % more_expr)
+            A("T nS[6], nP[6];")
+            fetch("nS", "nP", "npar", "ln", True)
+            _so_emit(self, _SO_XDOTS)
+            if bodies == "A":
+                _so_emit(self, "        {")
+                _so_emit(self, _SO_CASE_A, SUB="va")
+                _so_emit(self, "        }")
+            else:
+                _so_emit(self, "        {")
+                _so_emit(self, _SO_CASE_B, SUBX="(va && c != j)")
+                _so_emit(self, "        }\n        if (l != m) {")
+                _so_emit(self, _SO_CASE_C, SUB="va")
+                _so_emit(self, "        }")
+            A("l = ln; va = more; lpar = npar;")
+            A("#pragma unroll")
+            A("for (int r = 0; r < 6; r++) { xS[r] = nS[r]; xP[r] = nP[r]; }")
+            self.gen_add_end_control_flow()
+            self.gen_add_end_control_flow()
+        self.gen_add_end_control_flow()
+
+
 _SO_PREP = """
 T Pdd[6]; grid_mxm(Pdd, a, S); grid_mxm_peq(Pdd, v, Pd);
 // per-lane vectors of the reference's backward pass (:508-526): T1 = I^C S, T2 = -(B^C)^T S (bottom half zero), T3, T4, and I^C Pd
@@ -121,6 +221,7 @@ if (lane < @N@) { // record of joint `lane`: [S | Pd | Pdd]
     T *rec = &s_X[20*lane];
     #pragma unroll
     for (int r = 0; r < 6; r++) { rec[r] = S[r]; rec[6 + r] = Pd[r]; rec[12 + r] = Pdd[r]; }
+    @PARENT@
 }
 grid_wave_sync();
 const bool own = active && (lane < @N@)@NOSTORE@;
@@ -168,13 +269,15 @@ _SO_OPERATORS = """
     }
 """
 
+_SO_XDOTS = """
+        const T x_d1S = grid_dot6(xS, d1S), x_d3S = grid_dot6(xS, d3S), x_d2S = grid_dot6(xS, d2S), x_d4S = grid_dot6(xS, d4S);
+        const T x_d1P = grid_dot6(xS, d1P), x_d3P = grid_dot6(xS, d3P), x_d2P = grid_dot6(xS, d2P), x_d1PP = grid_dot6(xS, d1PP);
+"""
 _SO_X = """
         T xS[6], xP[6];
         #pragma unroll
         for (int r = 0; r < 6; r++) { xS[r] = s_X[20*l + r]; xP[r] = s_X[20*l + 6 + r]; }
-        const T x_d1S = grid_dot6(xS, d1S), x_d3S = grid_dot6(xS, d3S), x_d2S = grid_dot6(xS, d2S), x_d4S = grid_dot6(xS, d4S);
-        const T x_d1P = grid_dot6(xS, d1P), x_d3P = grid_dot6(xS, d3P), x_d2P = grid_dot6(xS, d2P), x_d1PP = grid_dot6(xS, d1PP);
-"""
+""" + _SO_XDOTS
 
 # joint j = l, ancestor-or-self an = m (reference phases t1..t5 and the p1/p2 terms, :566-710, :876-886); @SUB@ = "c is in the subtree of j (incl. j)"
 _SO_CASE_A = """
@@ -271,7 +374,7 @@ def gen_idsva_so_inner_chain(self, use_thread_group=False):
     _emit_link_setup(self)
     self.gen_add_code_line("const T qdd = (lane < %d) ? s_qdd[lane] : static_cast<T>(0);" % n)
     _emit_bias(self, True)
-    _so_emit(self, _SO_PREP)
+    _so_emit(self, _SO_PREP, PARENT="")
     _so_emit(self, """
 // structurally zero entries of dM_dq: dM_ik/dq_j with j <= min(i, k); the owner lane (largest index) writes them first
 #pragma unroll 1
@@ -280,6 +383,12 @@ for (int b = 0; b < @N@; b++) {
         if (own && b <= c) { mq[(c*@N@ + e)*@N@ + b] = static_cast<T>(0); mq[(b*@N@ + e)*@N@ + c] = static_cast<T>(0); }
     }
 }
+""")
+    if self.tuning["so_mapping"] == "balanced":
+        _so_emit_balanced_main(self, tree=False)
+        self.gen_add_end_function()
+        return
+    _so_emit(self, """
 // main loops: joint m supplies the vectors this lane's operators act on, joint l the vector the results are dotted with
 #pragma unroll 1
 for (int m = 0; m < @N@; m++) {""")
@@ -398,7 +507,11 @@ def gen_idsva_so_inner_tree(self, use_thread_group=False):
     self.gen_add_end_control_flow()
     self.gen_add_sync(use_thread_group)
     self.gen_add_end_control_flow()
-    _so_emit(self, _SO_PREP)
+    _so_emit(self, _SO_PREP, PARENT="rec[18] = static_cast<T>(par); // parent joint id (-1: base), read by the balanced main loops")
+    if self.tuning["so_mapping"] == "balanced":
+        _so_emit_balanced_main(self, tree=True)
+        self.gen_add_end_function()
+        return
     sub = lambda jv: "(c >= %s && c < %s + grid_so_tree_topology[%d*%s + 2])" % (jv, jv, K, jv)
     _so_emit(self, """
 // main loops: joint m supplies the vectors this lane's operators act on; joint l, on the same root path, the vector the results are dotted with

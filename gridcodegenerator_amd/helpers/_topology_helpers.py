@@ -99,6 +99,10 @@ def gen_model_constant_table(self):
         vals += fl
         self.gen_add_code_line("// tree topology for the second-order kernels, %d ints per lane: parent, tree level, subtree size, number of children, children" % K)
         self.gen_add_code_line("__device__ const int grid_so_tree_topology[%d] = {%s};" % (len(it), ", ".join(str(int(x)) for x in it)))
+    if self.gen_idsva_so_mode() is not None and self.tuning["so_mapping"] == "balanced":
+        it = self.gen_idsva_so_items_table()
+        self.gen_add_code_line("// work items (c, m) of the second-order main loops, [lane][slot] (algorithms/_idsva_so.py: gen_idsva_so_items)")
+        self.gen_add_code_line("__device__ const int grid_so_items[%d] = {%s};" % (len(it), ", ".join(str(int(x)) for x in it)))
     for ctype, sfx in (("float", "f"), ("double", "")):
         self.gen_add_code_line("__device__ const %s grid_model_constants_%s[%d] = {" % (ctype, ctype, len(vals)), True)
         for k in range(0, len(vals), 6):

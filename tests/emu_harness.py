@@ -21,7 +21,8 @@ def emu_library(robot, max_timesteps=64, cols_per_lane=None, tuning=None):
         out_dir = os.path.join(tempfile.gettempdir(), "grid_emu_build", key)
         generate_header(robot, out_dir, cols_per_lane=cols_per_lane, tuning=tuning)
         so = os.path.join(out_dir, "libgrid_emu_%s.so" % key)
-        cmd = ["g++", "-std=c++20", "-O0", "-g0", "-x", "c++", "-shared", "-fPIC", "-pthread", "-I" + EMU_INC, "-I" + out_dir, "-I" + INCLUDE_DIR,
+        cmd = ["g++", "-std=c++20", "-O0", "-g0", "-fno-gnu-unique",  # (no process-wide "unique" symbols: inline variables and function-local statics stay private to each robot library)
+               "-x", "c++", "-shared", "-fPIC", "-pthread", "-I" + EMU_INC, "-I" + out_dir, "-I" + INCLUDE_DIR,
                '-DGRID_ROBOT_NAME="%s"' % robot.name, "-Wno-unused-value", CAPI_SRC, "-o", so]
         subprocess.check_call(cmd)
         _CACHE[key] = so

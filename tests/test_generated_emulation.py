@@ -215,6 +215,26 @@ def test_emulated_idsva_so(name, libs, golden):
     lib.set_launch_dims(0, 0)
 
 
+@pytest.mark.parametrize("name", ["iiwa14", "tree12"])
+def test_emulated_idsva_so_subtree_mapping_variant(name, golden):
+    """tuning so_mapping = subtree (lane <-> subtree member, the round-1 mapping) stays available and gives the same tensors as the balanced item
+    mapping that ships (same arithmetic per entry, different lane executes it)."""
+    g = golden(name)
+    a = emu_library(name, max_timesteps=8)
+    b = emu_library(name, max_timesteps=8, tuning={"so_mapping": "subtree"})
+    n, N = a.n, 2
+    x = np.ascontiguousarray(np.hstack([g["q"], g["qd"], g["u"]]).astype(np.float32)[:N])
+    qdd = np.ascontiguousarray(g["qdd"].astype(np.float32)[:N])
+    outs = []
+    for lib in (a, b):
+        lib.set_launch_dims(0, 64)
+        out = np.full((N, 4 * n ** 3), np.nan, np.float32)
+        lib.idsva_so_device(x, qdd, N, out)
+        assert np.isfinite(out).all()
+        outs.append(out)
+    assert np.array_equal(outs[0], outs[1])
+
+
 @pytest.mark.parametrize("name,n", [("atlas", 30), ("mixed5", 5)])
 def test_emulated_second_order_is_refused_where_it_is_not_emitted(name, n, libs):
     """The 30-DoF humanoid's 4 n^3 record (432 KB per solve) does not fit the LDS staging of a CU (the reference's kernel needs ~500 KB of shared memory

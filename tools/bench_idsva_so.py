@@ -11,6 +11,8 @@ robot = RobotModel.from_fixture(name); n = robot.n
 for N in batches:
     import os
     lib = load(name, max_timesteps=N, build_dir=os.environ.get("GRID_SWEEP_BUILD_DIR"))
+    if os.environ.get("GRID_SWEEP_THREADS"):
+        lib.set_launch_dims(0, int(os.environ["GRID_SWEEP_THREADS"]))
     rng = np.random.default_rng(0)
     x = np.hstack([rng.uniform(-np.pi, np.pi, (N, n)), rng.uniform(-2, 2, (N, n)), rng.uniform(-10, 10, (N, n))]).astype(np.float32)
     d_in = torch.from_numpy(x).cuda(); d_qdd = torch.from_numpy(rng.uniform(-5, 5, (N, n)).astype(np.float32)).cuda()
