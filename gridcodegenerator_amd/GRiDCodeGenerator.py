@@ -30,6 +30,7 @@ TUNING_DEFAULTS = {
     "nt_store": True,           # non-temporal output stores
     "stagger": 0,               # forward_dynamics_gradient kernel: waves in odd wave slots of their SIMD start k*64 cycles late (0 = off), so that the two
                                 # waves of a SIMD do not load, compute and store in lock-step
+    "lds_pad": 0,               # occupancy experiment: extra elements per solve in the forward-dynamics-gradient slice of branch-frame robots
     "fast_sincos": True,        # fp32 joint angles: branch-free Cody-Waite + minimax polynomials (29 instructions) instead of the math library's sincosf (120)
     "composite_scan": "f32",    # f32 | f64: precision of the suffix sums of the link inertias (tip/branch-frame paths); f64 = exact sums, rounded once
     "base_origin": "auto",      # auto | off | <joint position>: tip-frame path - the joint-space inertia entries of the base half of a chain are
@@ -39,6 +40,7 @@ TUNING_ABLATION = {
     "debug_stop": 0,            # truncate the kernel after a phase / cycle stamps (tools/prof_ablation.sh, tools/phase_stamps.py)
     "no_pins": False,           # drop the register pins
     "no_wave_barrier": False,   # drop the wave barrier of grid_wave_sync (fences only)
+    "out_half": False,          # timing experiment: the output image of a solve overlaps its neighbour's (half the staging LDS, wrong results): what would more resident waves buy?
     "no_store": False,          # skip the final global store of every kernel (how much of a launch is the output leaving the chip?)
     "round_probe": (),          # accuracy diagnosis (tools/precision_probe.py): stages of the tip-frame inner whose results are rounded to fp32
                                 # inside the T = double instantiation - shows which stage's fp32 rounding the final error comes from

@@ -147,7 +147,7 @@ def gen_forward_dynamics_gradient_kernel(self, use_thread_group=False, use_qdd_M
     else:
         self.gen_add_code_line("T *s_q_qd_u = &s_mem[GRID_OFF_IN]; T *s_q = s_q_qd_u; T *s_qd = &s_q_qd_u[%d]; T *s_u = &s_q_qd_u[%d]; T *s_qdd = &s_mem[%s];" % (n, 2 * n, "FD_DU_OFF_QDD" if getattr(self, "branch_frame", False) else "GRID_OFF_QDD"))
     if getattr(self, "branch_frame", False) and not use_qdd_Minv_input:
-        self.gen_add_code_line("T *s_df_du = &s_out_all[grp*%d]; (void)s_qdd;" % (2 * n * n))
+        self.gen_add_code_line("T *s_df_du = &s_out_all[grp*%d]; (void)s_qdd;" % (n * n if self.tuning["out_half"] else 2 * n * n))
     else:
         self.gen_add_code_line("T *s_Minv = &s_mem[GRID_OFF_MINV]; T *s_df_du = &s_out_all[grp*%d]; (void)s_Minv; (void)s_qdd;" % (2 * n * n))
     if single_call_timing:

@@ -56,13 +56,13 @@ def gen_lds_layout(self):
     if getattr(self, "branch_frame", False):
         off["FD_SP"] = off["U"]
         off["FD_QDD"] = off["FD_SP"] + _pad4(self.branch_plan["sp_size"])
-        tot = off["FD_QDD"] + _pad4(n)
+        tot = off["FD_QDD"] + _pad4(n) + _pad4(int(self.tuning["lds_pad"]))
         if (tot // 4) % 2 == 0:
             tot += 4
         if tot > cur:
             off["TOTAL"] = cur = tot + (4 if ((tot // 4) % 2 == 0) else 0)
         off["FD_TOTAL"] = tot
-    off["OUT_PER_SOLVE"] = _pad4(2 * n * n)  # output staging, kept behind all slices (contiguous across the lane groups of a wave)
+    off["OUT_PER_SOLVE"] = _pad4(n * n if self.tuning["out_half"] else 2 * n * n)  # output staging, kept behind all slices (contiguous across the lane groups of a wave)
     return off
 
 
