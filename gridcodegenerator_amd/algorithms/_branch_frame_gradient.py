@@ -114,7 +114,7 @@ def gen_branch_frame_plan(self):
     # branch-free stores), then for the factors and the branch hand-over records as far as they fit; what does not goes behind the path axes
     if nnz + 4 > 20 * n:
         return None
-    place, x_at, sp_at = {"M": ("x", 0), "trash": ("x", nnz)}, nnz + 4, 6 * D * (nb + 1)
+    place, x_at, sp_at = {"M": ("x", 0), "trash": ("x", nnz)}, nnz + 4, 6 * D * nb
     for item, size in (("U", nnz), ("G", 28 * nb)):
         if x_at + size <= 20 * n:
             place[item] = ("x", x_at)
@@ -122,8 +122,19 @@ def gen_branch_frame_plan(self):
         else:
             place[item] = ("sp", sp_at)
             sp_at += size
-    return dict(branches=branches, br=br, pb=pb, level=level, paths=paths, joint_of_lane=joint_of_lane, kids=kids, comp_base=comp_base,
+    # one spare set of path records at the very end takes the (branch-free) stores of the lanes that are not the first of their branch; the
+    # kernels that have a result image in LDS send those stores to the head of the image instead (it is cleared after the frame chain), so
+    # the forward-dynamics-gradient kernel does not carry the spare set in its LDS slice
+    sp_spare, sp_at = sp_at, sp_at + 6 * D
+    return dict(sp_spare=sp_spare, branches=branches, br=br, pb=pb, level=level, paths=paths, joint_of_lane=joint_of_lane, kids=kids, comp_base=comp_base,
                 shapes=shapes, shape_of=shape_of, D=D, maxLb=max(len(J) for J in branches), maxlevel=max(level), maxchild=maxchild, row_len=row_len, nb=nb, ubase=ubase, mstart=mstart, nnz=nnz, place=place, sp_size=sp_at, factor_work=factor_work)
+
+
+def branch_spare_in_image(self, image_len):
+    """The lanes that are not the first of their branch send their (branch-free) path-record stores of the frame chain to the head of the
+    kernel's result image when that is large enough and one quad per lane clears it again; else to a spare set of records in s_SP."""
+    D = self.branch_plan["D"]
+    return image_len >= 6 * D and (6 * D + 3) // 4 <= self.lanes_per_solve
 
 
 def gen_branch_frame_constants(self):
@@ -343,7 +354,7 @@ def _emit_branch_inner(self, mode, use_thread_group=False):
                            "the caller must grid_wave_sync() before other lanes read the result"],
                           ["s_X is this solve's compact X(q) storage (the rotation blocks are read; once the frames are known it is re-used for the",
                            "     tree-sparse M, its factors and the branch hand-over records)",
-                           "s_SP is LDS scratch for the joint axes along the root path of every branch (6 values per path joint, plus one spare record per solve%s)" % ("" if all(v[0] == "x" for v in P["place"].values()) else "; then what does not fit into s_X: " + ", ".join(k for k, v in P["place"].items() if v[0] == "sp")),
+                           "s_SP is LDS scratch for the joint axes along the root path of every branch (6 values per path joint, plus one spare set of records per solve where the kernel has no result image to take them%s)" % ("" if all(v[0] == "x" for v in P["place"].values()) else "; then what does not fit into s_X: " + ", ".join(k for k, v in P["place"].items() if v[0] == "sp")),
                            "d_robotModel is the pointer to the initialized model specific helpers on the GPU",
                            "lane is the caller's lane index inside the solve's lane group"], None)
     A("template <typename T>")
@@ -383,9 +394,11 @@ def _emit_branch_inner(self, mode, use_thread_group=False):
           % (i, H + i, i, i, i, i, i, i, i, i))
     zero = {"fdgrad": ("s_df_du", 2 * n * n), "idgrad": ("s_dc_du", 2 * n * n), "minv": ("s_Minv", n * ld)}.get(mode)
     A("grid_wave_sync();")
+    spare_in_image = zero is not None and branch_spare_in_image(self, zero[1])
+    lanes_head = (6 * D + 3) // 4 if spare_in_image else 0  # quads at the head of the image that take the spare path records of the frame chain
     if zero is not None:
         A("// zero image of the result (unrelated joints, and rows outside the component of a column, stay exactly zero)")
-        A("for (int e = lane; e < %d; e += %d) {" % (zero[1] // 4, lanes), True)
+        A("for (int e = lane + %d; e < %d; e += %d) {" % (lanes_head, zero[1] // 4, lanes), True)
         A("#pragma unroll")
         A("for (int r = 0; r < 4; r++) { %s[4*e + r] = Z; }" % zero[0])
         self.gen_add_end_control_flow()
@@ -415,7 +428,8 @@ def _emit_branch_inner(self, mode, use_thread_group=False):
     A("T En[9]; // E(q) of the next path joint (parent -> child coordinates, row-major): read one step ahead")
     A("#pragma unroll")
     A("for (int r = 0; r < 9; r++) { En[r] = s_X[GRID_X_STRIDE*pj0 + r]; }")
-    A("T *s_sp_dst = (active && pos == 0) ? s_Sp : &s_SP[%d]; // the first lane of every branch parks the joint axes of the path; the others write to a spare record" % (6 * D * P["nb"]))
+    A("T *s_sp_dst = (active && pos == 0) ? s_Sp : %s; // the first lane of every branch parks the joint axes of the path; the others write to %s"
+      % ((zero[0], "the head of the result image (cleared below)") if spare_in_image else ("&s_SP[%d]" % P["sp_spare"], "a spare set of records")))
     for i in range(D):
         A("{ // path step %d" % i, True)
         A("T Ei[9];")
@@ -460,6 +474,12 @@ def _emit_branch_inner(self, mode, use_thread_group=False):
     self.gen_add_end_control_flow()
     _probe(self, "chain", "myR:9", "myp:3", "TR:9", "Tp:3", "gvec:3")
     self.gen_add_sync(use_thread_group)
+    if spare_in_image:
+        A("// (the head of the result image took the spare path records: clear it now)")
+        A("if (lane < %d) {" % lanes_head, True)
+        A("#pragma unroll")
+        A("for (int r = 0; r < 4; r++) { %s[4*lane + r] = Z; }" % zero[0])
+        self.gen_add_end_control_flow()
     # ------------------------------------------------------------------ own link: S, inertia in F_b
     TS(2)
     A("//")

@@ -54,10 +54,15 @@ def gen_lds_layout(self):
     off["FD_SP"] = off["FD_QDD"] = 0
     off["FD_TOTAL"] = cur
     if getattr(self, "branch_frame", False):
+        P = self.branch_plan
+        from ..algorithms._branch_frame_gradient import branch_spare_in_image
+        spare_in_image = branch_spare_in_image(self, 2 * n * n)  # (the spare path records of this kernel live in the head of its result image)
         off["FD_SP"] = off["U"]
-        off["FD_QDD"] = off["FD_SP"] + _pad4(self.branch_plan["sp_size"])
-        tot = off["FD_QDD"] + _pad4(n) + _pad4(int(self.tuning["lds_pad"]))
-        if (tot // 4) % 2 == 0:
+        off["FD_QDD"] = off["IN"] + 3 * n  # the qdd-input slot of the other overloads: unused by this kernel
+        tot = off["FD_SP"] + _pad4(P["sp_size"] - (6 * P["D"] if spare_in_image else 0)) + int(self.tuning["lds_pad"]) // 4 * 4
+        # lane groups of one wave read the same offset of different slices: with two groups per wave any stride that is not a multiple of
+        # the 64 banks keeps them apart; more groups want the odd multiple of 4 dwords
+        if (tot % 64 == 0) if 64 // self.lanes_per_solve <= 2 else ((tot // 4) % 2 == 0):
             tot += 4
         if tot > cur:
             off["TOTAL"] = cur = tot + (4 if ((tot // 4) % 2 == 0) else 0)

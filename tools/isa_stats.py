@@ -81,7 +81,8 @@ if __name__ == "__main__":
         tuning[k] = v
     path = asm_for(robot, tuning or None)
     for name, c in stats(path, only).items():
-        dem = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-cxxfilt", name], capture_output=True, text=True).stdout.strip()
+        filt = next((f for f in ("/opt/rocm/lib/llvm/bin/llvm-cxxfilt", "/usr/bin/c++filt") if os.path.exists(f)), None)
+        dem = subprocess.run([filt, name], capture_output=True, text=True).stdout.strip() if filt else name
         print(dem[:110])
         print("   ", c)
     print(path)
