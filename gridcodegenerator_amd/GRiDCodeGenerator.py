@@ -90,7 +90,7 @@ class GRiDCodeGenerator:
         gen_forward_dynamics_inner_function_call, gen_forward_dynamics_inner, gen_forward_dynamics_device, gen_forward_dynamics_kernel, \
         gen_forward_dynamics_host, gen_forward_dynamics, \
         gen_aba_inner_temp_mem_size, gen_aba_inner_function_call, gen_aba_inner, gen_aba_device, gen_aba_kernel, gen_aba_host, gen_aba, \
-        gen_idsva_so_available, gen_idsva_so_mode, gen_idsva_so_rec, gen_idsva_so_tree_tables, gen_idsva_so_items, gen_idsva_so_items_table, gen_idsva_so_lds_layout, gen_idsva_so_inner_temp_mem_size, gen_idsva_so_inner_function_call, gen_idsva_so_inner, gen_idsva_so_device, gen_idsva_so_kernel, gen_idsva_so_host, gen_idsva_so, \
+        gen_idsva_so_available, gen_idsva_so_mode, gen_idsva_so_direct, gen_idsva_so_rec, gen_idsva_so_tree_tables, gen_idsva_so_items, gen_idsva_so_items_table, gen_idsva_so_lds_layout, gen_idsva_so_inner_temp_mem_size, gen_idsva_so_inner_function_call, gen_idsva_so_inner, gen_idsva_so_device, gen_idsva_so_kernel, gen_idsva_so_host, gen_idsva_so, \
         gen_fdsva_so_inner_temp_mem_size, gen_fdsva_so_stage_size, gen_fdsva_so_inner, gen_fdsva_so_device, gen_fdsva_so_kernel, gen_fdsva_so_host, gen_fdsva_so, \
         gen_inverse_dynamics_gradient_inner_temp_mem_size, gen_inverse_dynamics_gradient_kernel_max_temp_mem_size, \
         gen_inverse_dynamics_gradient_inner_function_call, gen_inverse_dynamics_gradient_inner, gen_dc_du_to_lds, gen_gradient_slots, gen_gradient_outputs_decl, \
@@ -266,9 +266,15 @@ class GRiDCodeGenerator:
         self.gen_add_code_lines(["const int ID_DU_MAX_SHARED_MEM_COUNT = " + str(count) + ";",
                                  "const int FD_DU_MAX_SHARED_MEM_COUNT = " + str(count) + ";",
                                  "// (reference bookkeeping) derivative columns that are structurally non-zero: dv/da " + str(dva_cols) + ", df " + str(df_cols)])
-        self.gen_add_code_line("#define GRID_HAS_IDSVA_SO %d // second-order derivatives (idsva_so, fdsva_so): emitted for revolute-joint robots whose 4 n^3 record fits the LDS staging" % (1 if self.gen_idsva_so_available() else 0))
+        self.gen_add_code_line("#define GRID_HAS_IDSVA_SO %d // second-order derivatives (idsva_so, fdsva_so): emitted for fixed-base robots with revolute joints" % (1 if self.gen_idsva_so_available() else 0))
         if self.gen_idsva_so_available():
             sl_, scr_, stg_, thr_ = self.gen_idsva_so_lds_layout()
+            if scr_ > lds["MINV"] - lds["X"]:
+                raise ValueError("idsva_so scratch (%d) does not fit between X(q) and M^-1 of the general slice (fdsva_so_device runs it there)" % scr_)
+            self.gen_add_code_lines(["#define GRID_SO_DIRECT %d // 1: the 4 n^3 record of one solve does not fit LDS - idsva_so writes it entry by entry to global memory, fdsva_so_kernel takes a d_idsva_so workspace" % (1 if self.gen_idsva_so_direct() else 0),
+                                     "// init_gridData sizes the second-order buffers (d_idsva_so, d_df2 and their pinned host twins: 4 n^3 values per solve) for at most this many solves",
+                                     "// (1 GiB per buffer); the second-order host wrappers reject longer batches with hipErrorInvalidValue",
+                                     "template <typename T> constexpr int grid_so_max_timesteps() { return static_cast<int>((static_cast<size_t>(1) << 30)/(sizeof(T)*4*NUM_JOINTS*NUM_JOINTS*NUM_JOINTS)); }"])
             self.gen_add_code_lines(["const int IDSVA_SO_SUGGESTED_THREADS = %d; // idsva_so stages the 4 n^3 record of every solve in LDS: fewer solves per block" % thr_,
                                      "const int IDSVA_SO_LDS_PER_SOLVE = %d; // compact slice of the idsva_so kernels: q | qd | qdd | scratch" % sl_,
                                      "const int IDSVA_SO_SCRATCH_PER_SOLVE = %d; // X(q) / per-joint records + a zero qdd vector" % scr_,
@@ -324,9 +330,12 @@ class GRiDCodeGenerator:
             unused = [u for u in unused if u not in ("d_idsva_so", "h_idsva_so", "d_df2", "h_df2")]
         code = ["gridData<T> *hd_data = (gridData<T> *)malloc(sizeof(gridData<T>));",
                 "// device buffers of the dynamics algorithms"]
-        code += ["gpuErrchk(hipMalloc((void**)&hd_data->" + nm + ", static_cast<size_t>(NUM_TIMESTEPS)*" + sz + "*sizeof(T)));" for nm, sz in dev]
+        cnt = lambda nm: "SO_TIMESTEPS" if nm[2:] in ("idsva_so", "df2") else "NUM_TIMESTEPS"
+        if self.gen_idsva_so_available():
+            code += ["const int SO_TIMESTEPS = NUM_TIMESTEPS < grid_so_max_timesteps<T>() ? NUM_TIMESTEPS : grid_so_max_timesteps<T>(); // (second-order records: capped, see grid_so_max_timesteps)"]
+        code += ["gpuErrchk(hipMalloc((void**)&hd_data->" + nm + ", static_cast<size_t>(" + cnt(nm) + ")*" + sz + "*sizeof(T)));" for nm, sz in dev]
         code += ["// pinned host buffers (so the host wrappers' hipMemcpyAsync really is asynchronous)"]
-        code += ["gpuErrchk(hipHostMalloc((void**)&hd_data->" + nm + ", static_cast<size_t>(NUM_TIMESTEPS)*" + sz + "*sizeof(T), hipHostMallocDefault));" for nm, sz in host]
+        code += ["gpuErrchk(hipHostMalloc((void**)&hd_data->" + nm + ", static_cast<size_t>(" + cnt(nm) + ")*" + sz + "*sizeof(T), hipHostMallocDefault));" for nm, sz in host]
         code += ["// buffers of algorithms that this generator does not emit (kinematics, CRBA, second order) stay null"]
         code += ["hd_data->" + nm + " = nullptr;" for nm in unused]
         code += ["return hd_data;"]

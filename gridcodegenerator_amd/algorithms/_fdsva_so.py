@@ -16,7 +16,42 @@ first-order kernels (FDSVA_SO_SUGGESTED_THREADS).
 
 Parity: PARITY UNPINNED (the reference ships no oracle or vectors); oracle/fdsva_so_oracle.py restates the reference's contraction and is
 anchored on finite differences of the pinned first-order forward-dynamics-gradient oracle.
-Scope: every robot idsva_so is emitted for (gen_idsva_so_mode: serial revolute chains, and kinematic trees of revolute joints whose 4 n^3 record fits the LDS staging).
+Scope: every robot idsva_so is emitted for (gen_idsva_so_mode: serial revolute chains and kinematic trees of revolute joints; large robots keep the
+idsva_so tensors in a global workspace, gen_idsva_so_direct).
+"""
+
+
+# contraction for large robots: the register form below keeps 7 n values per lane and unrolls n^2 bodies; here only the 4 n output accumulators of one
+# (k, j) stay in registers, L and p are loops and the operands are re-read (LDS / L2) - n^4 multiply-adds either way
+_ROLLED = """
+const T *tqq = s_idsva_so, *tvv = s_idsva_so + @N3@, *tvq = s_idsva_so + 2*@N3@, *dM = s_idsva_so + 3*@N3@;
+const int j = (lane < @N@) ? lane : 0;
+const bool own = active && (lane < @N@);
+const T *fq_j = &s_df_du[j*@N@], *fv_j = &s_df_du[(@N@ + j)*@N@], *mi_j = &s_Minv[j*@LD@]; // column j of df/dq and of df/dqd, row j of M^-1
+#pragma unroll 1
+for (int k = 0; k < @N@; k++) {
+    const T *fq_k = &s_df_du[k*@N@];
+    T oq[@N@], oc[@N@], ov[@N@], ot[@N@]; // out_x[i][k][j], i = 0..n-1
+    #pragma unroll
+    for (int i = 0; i < @N@; i++) { oq[i] = oc[i] = ov[i] = ot[i] = static_cast<T>(0); }
+    #pragma unroll 1
+    for (int L = 0; L < @N@; L++) {
+        const T *dMk = &dM[(L*@N@ + k)*@N@], *dMj = &dM[(L*@N@ + j)*@N@];
+        T aq = tqq[(L*@N@ + k)*@N@ + j], ac = tvq[(L*@N@ + k)*@N@ + j], at = static_cast<T>(0);
+        const T av = tvv[(L*@N@ + k)*@N@ + j];
+        #pragma unroll 6
+        for (int p = 0; p < @N@; p++) { const T mk = dMk[p]; aq += dMj[p]*fq_k[p] + mk*fq_j[p]; ac += mk*fv_j[p]; at += mk*mi_j[p]; }
+        #pragma unroll
+        for (int i = 0; i < @N@; i++) { const T mi = s_Minv[L*@LD@ + i]; oq[i] += mi*aq; oc[i] += mi*ac; ov[i] += mi*av; ot[i] += mi*at; }
+    }
+    if (own) {
+        #pragma unroll
+        for (int i = 0; i < @N@; i++) {
+            const int e = (i*@N@ + k)*@N@ + j;
+            df2[e] = -oq[i]; df2[@N3@ + e] = -ov[i]; df2[2*@N3@ + e] = -oc[i]; df2[3*@N3@ + e] = -ot[i];
+        }
+    }
+}
 """
 
 
@@ -25,9 +60,10 @@ def gen_fdsva_so_inner_temp_mem_size(self):
 
 
 def gen_fdsva_so_stage_size(self):
-    """Per-solve staging behind the block's slices: df/du (2 n^2, padded) then the idsva_so tensors (4 n^3)."""
+    """Per-solve staging behind the block's slices: df/du (2 n^2, padded) then the idsva_so tensors (4 n^3; in the direct form of large robots they
+    stay in a global workspace, gen_idsva_so_direct)."""
     n = self.model.n
-    return (2 * n * n + 3) // 4 * 4 + 4 * n * n * n
+    return (2 * n * n + 3) // 4 * 4 + (0 if self.gen_idsva_so_direct() else 4 * n * n * n)
 
 
 def gen_fdsva_so_inner(self, use_thread_group=False):
@@ -37,14 +73,14 @@ def gen_fdsva_so_inner(self, use_thread_group=False):
     self.gen_add_func_doc("Second Order of Forward Dynamics with Spatial Vector Algebra: the contraction of the idsva_so tensors with M^-1 and df/du",
                           ["lane j produces the entries (., k, j) of the four output tensors and stores each exactly once; all lanes of the lane group must call it"],
                           ["df2 is the output record of this solve: 4*NUM_JOINTS^3 values [d2a_dqdq | d2a_dvdv | d2a_dvdq | d2a_dtdq] (global or LDS memory)",
-                           "s_idsva_so are the second derivative tensors of inverse dynamics at qdd = FD(q, qd, u), in LDS",
+                           "s_idsva_so are the second derivative tensors of inverse dynamics at qdd = FD(q, qd, u), in LDS (large robots: global workspace)",
                            "s_Minv is the dense symmetric inverse mass matrix in LDS (leading dimension GRID_MINV_LD)",
                            "s_df_du is the gradient of the forward dynamics in LDS ([col*n + row], col in [0, 2n))",
                            "lane is the caller's lane index inside the solve's lane group", "active is false for lane groups without a solve"], None)
     self.gen_add_code_line("template <typename T>")
     self.gen_add_code_line("__device__ __forceinline__")
     self.gen_add_code_line("void fdsva_so_inner(T *df2, const T *s_idsva_so, const T *s_Minv, const T *s_df_du, const int lane, const bool active) {", True)
-    lines = """
+    lines = (_ROLLED if n > 12 else """
 const T *tqq = s_idsva_so, *tvv = s_idsva_so + @N3@, *tvq = s_idsva_so + 2*@N3@, *dM = s_idsva_so + 3*@N3@;
 const int j = (lane < @N@) ? lane : 0;
 const bool own = active && (lane < @N@);
@@ -76,7 +112,7 @@ for (int k = 0; k < @N@; k++) {
         }
     }
 }
-""".replace("@N3@", str(n3)).replace("@N@", str(n)).replace("@LD@", str(ld))
+""").replace("@N3@", str(n3)).replace("@N@", str(n)).replace("@LD@", str(ld))
     for line in lines.strip("\n").split("\n"):
         self.gen_add_code_line(line)
     self.gen_add_end_function()
@@ -88,7 +124,7 @@ def gen_fdsva_so_device(self, use_thread_group=False):
                           ["all lanes of the solve's lane group must call it; s_df_du holds the first-order gradient on return (reference algorithms/_fdsva_so.py:147-156)"],
                           ["df2 is the output record of this solve: 4*NUM_JOINTS^3 values (global or LDS memory)",
                            "s_df_du is a pointer to LDS for the derivative of forward dynamics WRT q,qd of size 2*NUM_JOINTS*NUM_JOINTS = " + str(2 * n * n),
-                           "s_idsva_so is a pointer to LDS for the 4*NUM_JOINTS^3 second derivative tensors of inverse dynamics",
+                           "s_idsva_so is a pointer to LDS (large robots: to a global workspace) for the 4*NUM_JOINTS^3 second derivative tensors of inverse dynamics",
                            "s_q is the vector of joint positions", "s_qd is the vector of joint velocities", "s_u is the vector of joint control inputs",
                            "s_work is this solve's LDS workspace of GRID_LDS_PER_SOLVE elements",
                            "d_robotModel is the pointer to the initialized model specific helpers on the GPU (XImats, topology_helpers, etc.)",
@@ -101,7 +137,7 @@ def gen_fdsva_so_device(self, use_thread_group=False):
     self.gen_add_code_line("forward_dynamics_gradient_device<T>(s_df_du, s_q, s_qd, s_u, s_work, d_robotModel, gravity, lane);")
     self.gen_add_code_line("forward_dynamics_device<T>(s_qdd, s_q, s_qd, s_u, s_work, d_robotModel, gravity, lane);")
     self.gen_add_code_line("direct_minv_device<T>(s_Minv, s_q, s_work, d_robotModel, lane);")
-    self.gen_add_code_line("idsva_so_device<T>(s_idsva_so, s_q, s_qd, s_qdd, &s_work[GRID_OFF_X], d_robotModel, gravity, lane, true);")
+    self.gen_add_code_line("idsva_so_device<T>(s_idsva_so, s_q, s_qd, s_qdd, &s_work[GRID_OFF_X], d_robotModel, gravity, lane, %s);" % ("active" if self.gen_idsva_so_direct() else "true"))
     self.gen_add_sync(use_thread_group)
     self.gen_add_code_line("fdsva_so_inner<T>(df2, s_idsva_so, s_Minv, s_df_du, lane, active);")
     self.gen_add_end_function()
@@ -116,7 +152,10 @@ def gen_fdsva_so_kernel(self, use_thread_group=False, single_call_timing=False):
                    "d_robotModel is the pointer to the initialized model specific helpers on the GPU (XImats, topology_helpers, etc.)",
                    "gravity is the gravity constant",
                    "num_timesteps is the length of the trajectory points we need to compute over (or overloaded as test_iters for timing)"]
-    func_def = "void fdsva_so_kernel(T *d_df2, const T *d_q_qd_u, const int stride_q_qd_u, const robotModel<T> *d_robotModel, const T gravity, const int NUM_TIMESTEPS) {"
+    direct = self.gen_idsva_so_direct()
+    func_def = "void fdsva_so_kernel(T *d_df2, " + ("T *d_idsva_so, " if direct else "") + "const T *d_q_qd_u, const int stride_q_qd_u, const robotModel<T> *d_robotModel, const T gravity, const int NUM_TIMESTEPS) {"
+    if direct:
+        func_params.insert(1, "d_idsva_so is a workspace of 4*NUM_JOINTS^3 values per solve (the idsva_so tensors of a solve do not fit LDS; gridData::d_idsva_so): it holds them on return")
     if single_call_timing:
         func_def = func_def.replace("kernel(", "kernel_single_timing(")
     self.gen_add_func_doc("Second Order of Forward Dynamics with Spatial Vector Algebra",
@@ -127,7 +166,7 @@ def gen_fdsva_so_kernel(self, use_thread_group=False, single_call_timing=False):
     self.gen_add_code_line(func_def, True)
     self.gen_kernel_prologue("GRID_LDS_PER_SOLVE", "FDSVA_SO_MAX_SOLVES_PER_BLOCK")
     self.gen_add_code_lines(["T *s_q_qd_u = &s_mem[GRID_OFF_IN]; T *s_q = s_q_qd_u; T *s_qd = &s_q_qd_u[%d]; T *s_u = &s_q_qd_u[%d];" % (n, 2 * n),
-                             "T *s_df_du = &s_out_all[grp*%d]; T *s_idsva_so = s_df_du + %d;" % (stage, stage - 4 * n3)])
+                             "T *s_df_du = &s_out_all[grp*%d];" % stage + ("" if direct else " T *s_idsva_so = s_df_du + %d;" % (stage - 4 * n3))])
     if single_call_timing:
         self.gen_add_code_line("const int k = 0; const int kc = 0; const bool valid = (blockIdx.x + blockIdx.y == 0) && (grp == 0); const int lane = lane_id;")
         self.gen_add_code_line("if (!valid) {return;}")
@@ -137,6 +176,8 @@ def gen_fdsva_so_kernel(self, use_thread_group=False, single_call_timing=False):
     if single_call_timing:
         self.gen_add_code_line("for (int rep = 0; rep < NUM_TIMESTEPS; rep++){", True)
     self.gen_add_code_line("// compute; the record of solve k goes straight to global memory")
+    if direct:
+        self.gen_add_code_line("T *s_idsva_so = &d_idsva_so[static_cast<size_t>(kc)*%d]; // (global workspace; lane groups without a solve never write through it)" % (4 * n3))
     self.gen_add_code_line("fdsva_so_device<T>(&d_df2[static_cast<size_t>(kc)*%d], s_df_du, s_idsva_so, s_q, s_qd, s_u, s_mem, d_robotModel, gravity, lane, valid);" % (4 * n3))
     self.gen_add_sync(use_thread_group)
     if single_call_timing:
@@ -161,6 +202,7 @@ def gen_fdsva_so_host(self, mode=0):
     self.gen_add_code_line("void " + name + "(gridData<T> *hd_data, const robotModel<T> *d_robotModel, const T gravity, const int num_timesteps,")
     self.gen_add_code_line("                      const dim3 block_dimms, const dim3 thread_dimms" + ("" if compute_only else ", hipStream_t *streams") + ") {", True)
     self.gen_add_code_line("int stride_q_qd_u = 3*NUM_JOINTS;")
+    self.gen_add_code_line("if (num_timesteps > grid_so_max_timesteps<T>()) {gpuErrchk(hipErrorInvalidValue); return;} // (beyond what init_gridData allocates for second-order records)")
     cnt = "" if single_call_timing else "num_timesteps*"
     if not compute_only:
         self.gen_add_code_lines(["// start code with memory transfer",
@@ -170,7 +212,7 @@ def gen_fdsva_so_host(self, mode=0):
     self.gen_add_code_line("// then call the kernel")
     if single_call_timing:
         self.gen_add_code_line("struct timespec start, end; clock_gettime(CLOCK_MONOTONIC,&start);")
-    self.gen_add_code_lines(["hipLaunchKernelGGL((" + kern + "),block_dimms,thread_dimms,grid_lds_bytes<T>(thread_dimms, GRID_LDS_PER_SOLVE, FDSVA_SO_STAGE_PER_SOLVE, FDSVA_SO_MAX_SOLVES_PER_BLOCK),0,hd_data->d_df2,hd_data->d_q_qd_u,stride_q_qd_u,d_robotModel,gravity,num_timesteps);",
+    self.gen_add_code_lines(["hipLaunchKernelGGL((" + kern + "),block_dimms,thread_dimms,grid_lds_bytes<T>(thread_dimms, GRID_LDS_PER_SOLVE, FDSVA_SO_STAGE_PER_SOLVE, FDSVA_SO_MAX_SOLVES_PER_BLOCK),0,hd_data->d_df2," + ("hd_data->d_idsva_so," if self.gen_idsva_so_direct() else "") + "hd_data->d_q_qd_u,stride_q_qd_u,d_robotModel,gravity,num_timesteps);",
                              "gpuErrchk(hipGetLastError()); gpuErrchk(hipDeviceSynchronize());"])
     if single_call_timing:
         self.gen_add_code_line("clock_gettime(CLOCK_MONOTONIC,&end);")

@@ -21,26 +21,32 @@ joint (crm/crf/icrf matrices, D1..D4, outer products t1..t9, p1..p6, :473-911) a
 
 Parity: the reference ships no oracle or vectors for this algorithm (PARITY UNPINNED); the tests compare with the NumPy restatement of
 the reference's emitter, which is itself anchored on finite differences of the pinned first-order oracle.
-Scope this round: single serial chains of revolute joints (self.tip_frame and one chain); other robots do not get the idsva_so surface.
+Scope: fixed-base robots with revolute joints (gen_idsva_so_mode: chain form, tree form; gen_idsva_so_direct for records beyond the LDS of a CU).
 """
 from ._tip_frame_gradient import _chain_step, _emit_bias, _emit_body_terms, _emit_chain_decls, _emit_link_constants_load, _emit_link_inertia, _emit_link_setup
 
 
 def gen_idsva_so_mode(self):
     """"chain": a single serial chain of revolute joints - the tip-frame formulation (lane scans, no LDS hand-offs in the set-up);
-    "tree": any other fixed-base robot with revolute joints whose 4 n^3 record fits the LDS staging - one common (base) frame, the kinematics
+    "tree": any other fixed-base robot with revolute joints - one common (base) frame, the kinematics
     and the subtree composites travel level by level through LDS (reference: get_parent_id tables, algorithms/_idsva_so.py:171-193,264-284,320-340);
-    None: not emitted (prismatic joints; records beyond the LDS of a CU, e.g. 30 joints: 432 KB per solve - the reference's own kernel keeps
-    4 n^3 + 390 n + 36 |pairs| values in shared memory, ~500 KB there, and cannot be launched on any GPU either)."""
+    None: not emitted (prismatic joints).  Records beyond the LDS of a CU (30 joints: 432 KB per solve - the reference's own kernel keeps
+    4 n^3 + 390 n + 36 |pairs| values in shared memory, ~500 KB there, and cannot be launched on any GPU) are written straight to global
+    memory: gen_idsva_so_direct()."""
     if getattr(self, "tip_frame", False) and self.tip_nseg == 1:
         return "chain"
     m = self.model
     if self.cols_per_lane != 2 or any(s_ >= 3 for s_ in m.S_index):
         return None
-    n, G = m.n, self.lanes_per_solve
-    if (28 * n + 4 * n + 16 + 4 * n * n * n) * 4 > 150 * 1024:
-        return None
     return "tree"
+
+
+def gen_idsva_so_direct(self):
+    """True where the 4 n^3 record of one solve does not fit the LDS staging next to the slice: the kernels then write every entry straight to
+    the solve's record in global memory (store-issue bound, see the module docstring - but the only way for large robots), and fdsva_so reads the
+    idsva_so tensors back from a global workspace (gridData::d_idsva_so) instead of LDS."""
+    n = self.model.n
+    return self.gen_idsva_so_mode() is not None and (28 * n + 4 * n + 16 + 4 * n * n * n) * 4 > 150 * 1024
 
 
 def gen_idsva_so_available(self):
@@ -67,7 +73,7 @@ def gen_idsva_so_lds_layout(self):
     sl = pad4(3 * n) + scratch
     if (sl // 4) % 2 == 0:
         sl += 4
-    stage = 4 * n * n * n
+    stage = 0 if self.gen_idsva_so_direct() else 4 * n * n * n
     threads = 64
     while threads > G and (threads // G) * (sl + stage) * 4 > 150 * 1024:
         threads -= G
@@ -572,7 +578,7 @@ def gen_idsva_so_kernel(self, use_thread_group=False, use_qdd_input=False, singl
     if single_call_timing:
         func_def = func_def.replace("kernel(", "kernel_single_timing(")
     self.gen_add_func_doc("Computes the second order derivatives of inverse dynamics",
-                          ["launch with IDSVA_SO_SUGGESTED_THREADS threads and IDSVA_SO_DYNAMIC_SHARED_MEM_COUNT*sizeof(T) bytes of dynamic LDS: the 4 n^3 record of every solve is staged in LDS"], func_params, None)
+                          ["launch with IDSVA_SO_SUGGESTED_THREADS threads and IDSVA_SO_DYNAMIC_SHARED_MEM_COUNT*sizeof(T) bytes of dynamic LDS" + (": the 4 n^3 record of every solve is staged in LDS" if not self.gen_idsva_so_direct() else "; the 4 n^3 record of a solve does not fit LDS and is written entry by entry to global memory")], func_params, None)
     self.gen_add_code_line("template <typename T>")
     self.gen_add_code_line("__global__ GRID_LAUNCH_BOUNDS")
     self.gen_add_code_line(func_def, True)
@@ -580,7 +586,9 @@ def gen_idsva_so_kernel(self, use_thread_group=False, use_qdd_input=False, singl
     pad3n = (3 * n + 3) // 4 * 4
     self.gen_kernel_prologue("IDSVA_SO_LDS_PER_SOLVE", "IDSVA_SO_MAX_SOLVES_PER_BLOCK")
     self.gen_add_code_line("T *s_q_qd_u = s_mem; T *s_q = s_q_qd_u; T *s_qd = &s_q_qd_u[%d]; T *s_qdd = &s_q_qd_u[%d]; T *s_scratch = &s_mem[%d]; (void)s_qdd;" % (n, 2 * n, pad3n))
-    self.gen_add_code_line("T *s_idsva_so = &s_out_all[grp*%d]; // this solve's output record, staged in LDS" % stage)
+    direct = self.gen_idsva_so_direct()
+    if not direct:
+        self.gen_add_code_line("T *s_idsva_so = &s_out_all[grp*%d]; // this solve's output record, staged in LDS" % stage)
     if single_call_timing:
         self.gen_add_code_line("const int k = 0; const int kc = 0; const bool valid = (blockIdx.x + blockIdx.y == 0) && (grp == 0); const int lane = lane_id;")
         self.gen_add_code_line("if (!valid) {return;}")
@@ -593,10 +601,17 @@ def gen_idsva_so_kernel(self, use_thread_group=False, use_qdd_input=False, singl
     if single_call_timing:
         self.gen_add_code_line("for (int rep = 0; rep < NUM_TIMESTEPS; rep++){", True)
     self.gen_add_code_line("// compute")
-    self.gen_add_code_line("idsva_so_device<T>(s_idsva_so, s_q, s_qd, " + ("s_qdd, " if use_qdd_input else "") + "s_scratch, d_robotModel, gravity, lane, true);")
+    if direct:
+        self.gen_add_code_line("// (the record of one solve is larger than the LDS of a CU: every entry goes straight to global memory)")
+        self.gen_add_code_line("idsva_so_device<T>(&d_idsva_so[static_cast<size_t>(kc)*%d], s_q, s_qd, " % (4 * n3) + ("s_qdd, " if use_qdd_input else "") + "s_scratch, d_robotModel, gravity, lane, valid);")
+        self.gen_add_sync(use_thread_group)
+    else:
+        self.gen_add_code_line("idsva_so_device<T>(s_idsva_so, s_q, s_qd, " + ("s_qdd, " if use_qdd_input else "") + "s_scratch, d_robotModel, gravity, lane, true);")
     if single_call_timing:
         self.gen_add_end_control_flow()
-    if single_call_timing:
+    if direct:
+        pass
+    elif single_call_timing:
         self.gen_kernel_save_result_single_timing("idsva_so", 4 * n3, use_thread_group)
     else:
         self.gen_kernel_save_result("idsva_so", 4 * n3, 4 * n3, use_thread_group)
@@ -621,6 +636,7 @@ def gen_idsva_so_host(self, mode=0):
     self.gen_add_code_line("void " + name + "(gridData<T> *hd_data, const robotModel<T> *d_robotModel, const T gravity, const int num_timesteps,")
     self.gen_add_code_line("                      const dim3 block_dimms, const dim3 thread_dimms" + ("" if compute_only else ", hipStream_t *streams") + ") {", True)
     self.gen_add_code_line("int stride_q_qd = 3*NUM_JOINTS;")
+    self.gen_add_code_line("if (num_timesteps > grid_so_max_timesteps<T>()) {gpuErrchk(hipErrorInvalidValue); return;} // (beyond what init_gridData allocates for second-order records)")
     cnt = "" if single_call_timing else "num_timesteps*"
     if not compute_only:
         self.gen_add_code_lines(["// start code with memory transfer",

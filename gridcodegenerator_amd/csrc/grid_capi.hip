@@ -142,10 +142,23 @@ template <typename T>
 static size_t grid_data_bytes(int N) {
     const size_t n = grid::NUM_JOINTS;
     size_t per = 3 * n + 2 * n + n + n + n * n + n + 2 * n * n + 2 * n * n;
+    size_t bytes = per * (size_t)N * sizeof(T);
 #if GRID_HAS_IDSVA_SO
-    per += 8 * n * n * n;
+    const int so = N < grid::grid_so_max_timesteps<T>() ? N : grid::grid_so_max_timesteps<T>();
+    bytes += 8 * n * n * n * (size_t)so * sizeof(T);
 #endif
-    return per * (size_t)N * sizeof(T);
+    return bytes;
+}
+
+// solves per call the second-order entry points of this handle accept (their records are 4 n^3 values: init_gridData caps those buffers)
+template <typename T>
+static int so_capacity(const grid_handle *h) {
+#if GRID_HAS_IDSVA_SO
+    return h->max_timesteps < grid::grid_so_max_timesteps<T>() ? h->max_timesteps : grid::grid_so_max_timesteps<T>();
+#else
+    (void)h;
+    return 0;
+#endif
 }
 
 template <typename T>
@@ -299,7 +312,13 @@ static int fdsva_so_device(grid_handle *h, const T *d_q_qd_u, int stride, int N,
     if ((rc = ensure_typed<T>(h))) return rc;
     launch_cfg c;
     if ((rc = make_launch<T>(h, N, grid::FDSVA_SO_SUGGESTED_THREADS, grid::FDSVA_SO_MAX_SOLVES_PER_BLOCK, grid::GRID_LDS_PER_SOLVE, grid::FDSVA_SO_STAGE_PER_SOLVE, &c))) return rc;
+#if GRID_SO_DIRECT
+    // the idsva_so tensors of a solve do not fit LDS: the kernel keeps them in the handle's d_idsva_so buffer
+    if (N > so_capacity<T>(h)) return fail_msg(hipErrorInvalidValue, "num_timesteps exceeds the handle's second-order workspace (grid_second_order_capacity)");
+    hipLaunchKernelGGL((grid::fdsva_so_kernel<T>), c.grid, c.block, c.lds, (hipStream_t)stream, d_df2, typed<T>(h).hd_data->d_idsva_so, d_q_qd_u, stride, typed<T>(h).d_robotModel, gravity, N);
+#else
     hipLaunchKernelGGL((grid::fdsva_so_kernel<T>), c.grid, c.block, c.lds, (hipStream_t)stream, d_df2, d_q_qd_u, stride, typed<T>(h).d_robotModel, gravity, N);
+#endif
     GRID_TRY(hipGetLastError());
     return 0;
 #else
@@ -420,6 +439,7 @@ static int so_host(grid_handle *h, const T *h_q_qd_u, const T *h_qdd, int N, T g
     if (rc) return rc;
 #if GRID_HAS_IDSVA_SO
     if (N == 0) return 0;
+    if (N > so_capacity<T>(h)) return fail_msg(hipErrorInvalidValue, "num_timesteps exceeds the handle's second-order buffers (grid_second_order_capacity)");
     const size_t n = grid::NUM_JOINTS;
     GRID_ON_DEVICE(h);
     if ((rc = ensure_typed<T>(h))) return rc;
@@ -487,6 +507,7 @@ int grid_lanes_per_solve(void) { return grid::GRID_LANES_PER_SOLVE; }
 int grid_suggested_threads(void) { return grid::SUGGESTED_THREADS; }
 int grid_lds_bytes_per_block(void) { return grid::FD_DU_DYNAMIC_SHARED_MEM_COUNT * (int)sizeof(float); }
 int grid_has_second_order(void) { return GRID_HAS_IDSVA_SO; }
+int grid_second_order_capacity(const grid_handle *h, int f64) { return h ? (f64 ? so_capacity<double>(h) : so_capacity<float>(h)) : 0; }
 const char *grid_last_error(void) { return g_err; }
 
 int grid_init(int device, int max_timesteps, grid_handle **out) {

@@ -105,7 +105,7 @@ class GridLibrary:
         self.path = path
         self.lib = ctypes.CDLL(path)
         L = self.lib
-        if not hasattr(L, "grid_forward_dynamics_gradient_multi_host"):
+        if not hasattr(L, "grid_second_order_capacity"):
             raise GridError("%s was built from an older grid_capi.hip - rebuild it (gridcodegenerator_amd.runtime.build_library)" % path)
         L.grid_robot_name.restype = ctypes.c_char_p
         L.grid_last_error.restype = ctypes.c_char_p
@@ -118,6 +118,10 @@ class GridLibrary:
         self.handle = ctypes.c_void_p()
         self._check(L.grid_init(ctypes.c_int(device), ctypes.c_int(max_timesteps), ctypes.byref(self.handle)))
         self.max_timesteps = max_timesteps
+
+    def second_order_capacity(self, f64=False):
+        """Solves per call the second-order entry points accept on this handle (their buffers are capped at 1 GiB each)."""
+        return self.lib.grid_second_order_capacity(self.handle, ctypes.c_int(1 if f64 else 0))
 
     def _check(self, rc):
         if rc != 0:

@@ -48,6 +48,9 @@ int grid_init(int device, int max_timesteps, grid_handle **out);
 int grid_close(grid_handle *h);
 /* device the handle was created on (-1 for NULL) */
 int grid_device(const grid_handle *h);
+/* solves per call the second-order entry points accept on this handle: min(max_timesteps, 1 GiB / record) - the generated init_gridData<T>()
+ * caps the d_idsva_so / d_df2 buffers (4 n^3 values per solve; grid_so_max_timesteps<T>() of the generated header).  f64 != 0: the _f64 forms */
+int grid_second_order_capacity(const grid_handle *h, int f64);
 
 /* replaces forward_dynamics_gradient<T,false>(hd_data, d_robotModel, gravity, num_timesteps, block, thread, streams)
  * (reference algorithms/_forward_dynamics_gradient.py:186-249): host buffers in, host buffers out, synchronous */
@@ -80,7 +83,9 @@ int grid_idsva_so_device(grid_handle *h, const float *d_q_qd_u, int stride_q_qd_
                          float *d_idsva_so, void *stream);
 /* replaces fdsva_so_kernel<T> (reference algorithms/_fdsva_so.py:159-230): second-order derivatives of forward dynamics, 4 n^3 values per solve
  * [d2a_dqdq | d2a_dvdv | d2a_dvdq | d2a_dtdq].  hipErrorNotSupported when grid_has_second_order() == 0; launches with at most
- * FDSVA_SO_SUGGESTED_THREADS threads per block whatever grid_set_launch_dims() says */
+ * FDSVA_SO_SUGGESTED_THREADS threads per block whatever grid_set_launch_dims() says.  Robots whose 4 n^3 record is larger than the LDS of a
+ * CU (30 joints: 432 KB; GRID_SO_DIRECT of the generated header) keep the idsva_so tensors in the handle's own workspace: num_timesteps must
+ * not exceed grid_second_order_capacity() and calls on one handle must not overlap */
 int grid_fdsva_so_device(grid_handle *h, const float *d_q_qd_u, int stride_q_qd_u, int num_timesteps, float gravity, float *d_df2, void *stream);
 /* replaces inverse_dynamics_gradient_kernel<T> (reference algorithms/_inverse_dynamics_gradient.py:817-888); d_qdd may be NULL */
 int grid_inverse_dynamics_gradient_device(grid_handle *h, const float *d_q_qd, int stride_q_qd, const float *d_qdd, int num_timesteps, float gravity,

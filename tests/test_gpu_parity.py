@@ -298,9 +298,10 @@ def test_non_default_generation_variants_on_gpu(tuning, torch_cuda, golden, tmp_
     lib.close()
 
 
-@pytest.mark.parametrize("name", ["iiwa14", "arm6", "chain12", "chain8", "hyq", "tree12"])
+@pytest.mark.parametrize("name", ["iiwa14", "arm6", "chain12", "chain8", "hyq", "tree12", "atlas"])
 def test_idsva_so_matches_the_restated_reference_algorithm(name, torch_cuda, libs, golden):
-    """SURVEY.md section 8(f) rank 3 (serial chains: tip-frame form; the quadruped and the 12-DoF tree: tree form): second-order inverse-dynamics derivatives on the GPU vs the NumPy restatement of the
+    """SURVEY.md section 8(f) rank 3 (serial chains: tip-frame form; the quadruped, the 12-DoF tree and the 30-DoF humanoid: tree form - the humanoid's
+    432 KB record goes entry by entry to global memory, GRID_SO_DIRECT): second-order inverse-dynamics derivatives on the GPU vs the NumPy restatement of the
     reference's emitter (oracle/idsva_so_oracle.py - parity unpinned, anchored on finite differences of the pinned first-order oracle)."""
     from gridcodegenerator_amd.robot import DuckRobot
     from oracle.idsva_so_oracle import idsva_so
@@ -334,18 +335,30 @@ def test_idsva_so_matches_the_restated_reference_algorithm(name, torch_cuda, lib
     assert np.array_equal(out2.cpu().numpy(), got)
 
 
-def test_second_order_is_refused_where_the_record_does_not_fit(torch_cuda, libs):
-    """30 joints: 4 n^3 = 432 KB per solve does not fit the LDS of a CU (the reference's kernel would need ~500 KB of shared memory)."""
+def test_second_order_is_refused_for_prismatic_joints_and_beyond_the_handles_capacity(torch_cuda, libs):
+    """Robots with prismatic joints are outside the second-order scope (hipErrorNotSupported); the 30-DoF humanoid's records are 432 KB per solve:
+    the generated init_gridData caps the second-order buffers at 1 GiB each and the C ABI rejects longer batches instead of overrunning them."""
     from gridcodegenerator_amd.runtime import GridError
 
     torch = torch_cuda
-    lib = libs("atlas")
+    lib = libs("mixed5")
     assert not lib.has_second_order
     with pytest.raises(GridError):
-        lib.idsva_so_device(torch.zeros((1, 90), device="cuda"), None, 1, torch.zeros((1, 4), device="cuda"))
+        lib.idsva_so_device(torch.zeros((1, 15), device="cuda"), None, 1, torch.zeros((1, 4), device="cuda"))
+    big = GridLibrary(build_library("atlas"), device=0, max_timesteps=4096)
+    try:
+        assert big.has_second_order
+        cap = big.second_order_capacity()
+        assert cap == (1 << 30) // (4 * 4 * 30 ** 3) and big.second_order_capacity(f64=True) == cap // 2
+        with pytest.raises(GridError):
+            big.fdsva_so_host(np.zeros((cap + 1, 90), np.float32))
+        with pytest.raises(GridError):
+            big.fdsva_so_device(torch.zeros((cap + 1, 90), device="cuda"), cap + 1, torch.zeros((1, 4), device="cuda"))
+    finally:
+        big.close()
 
 
-@pytest.mark.parametrize("name", ["iiwa14", "arm6", "chain12", "chain8", "hyq", "tree12"])
+@pytest.mark.parametrize("name", ["iiwa14", "arm6", "chain12", "chain8", "hyq", "tree12", "atlas"])
 def test_fdsva_so_matches_the_restated_reference_algorithm(name, torch_cuda, libs, golden):
     """Second half of SURVEY.md section 8(f) rank 3 (serial revolute chains): second-order forward-dynamics derivatives on the GPU vs the NumPy
     restatements of the reference's idsva_so + fdsva_so emitters fed by the pinned first-order oracle (parity unpinned)."""
@@ -509,6 +522,37 @@ def test_double_precision_c_abi_on_the_gpu(name, torch_cuda, golden):
         assert per_solve_err(lib.host_f64("aba", x), g["qdd"]) <= 1e-9
         out32 = lib.forward_dynamics_gradient_host(x.astype(np.float32))  # float and double state of one handle side by side
         assert per_solve_err(out32, col("df_du")) <= TOL
+    finally:
+        lib.close()
+
+
+@pytest.mark.parametrize("name", ["hyq", "atlas"])
+def test_double_precision_second_order_on_branched_robots(name, torch_cuda, golden):
+    """idsva_so / fdsva_so of the tree form in T = double through the C ABI, to rounding level against the restated reference algorithm (the quadruped
+    stages its records in LDS, the humanoid writes them straight to global memory and reads the idsva_so tensors back from the handle's workspace)."""
+    from gridcodegenerator_amd.robot import DuckRobot
+    from oracle.fdsva_so_oracle import fdsva_so
+    from oracle.idsva_so_oracle import idsva_so
+    from oracle.rbd_oracle import Oracle
+
+    g = golden(name)
+    lib = GridLibrary(build_library(name), device=0, max_timesteps=16)
+    try:
+        n, N = lib.n, 4
+        x = np.hstack([g["q"], g["qd"], g["u"]]).astype(np.float64)[:N]
+        qdd_in = g["qdd"][:N].astype(np.float64)
+        robot = RobotModel.from_fixture(name)
+        model, orc = DuckRobot(robot), Oracle(robot)
+        got_id = lib.host_f64("idsva_so", x, qdd_in)
+        got_fd = lib.host_f64("fdsva_so", x)
+        for k in range(N):
+            q, qd, u = (x[k, i * n:(i + 1) * n] for i in range(3))
+            ref = np.concatenate([t.reshape(-1) for t in idsva_so(model, q, qd, qdd_in[k])])
+            assert np.abs(got_id[k] - ref).max() <= 1e-9 * max(np.abs(ref).max(), 1.0), k
+            df_du, qdd, Minv, _ = orc.fd_grad(q, qd, u, full=True)
+            so = np.concatenate([t.reshape(-1) for t in idsva_so(model, q, qd, qdd)])
+            ref2 = fdsva_so(so, Minv, df_du).reshape(-1)
+            assert np.abs(got_fd[k] - ref2).max() <= 1e-9 * max(np.abs(ref2).max(), 1.0), k
     finally:
         lib.close()
 

@@ -23,7 +23,7 @@ def finite_difference_tensors(orc, n, q, qd, qdd, h=1e-5):
     return dq2, dqd2, dvdq, dMdq
 
 
-@pytest.mark.parametrize("name", ["iiwa14", "arm6", "hyq", "tree12"])
+@pytest.mark.parametrize("name", ["iiwa14", "arm6", "hyq", "tree12", "atlas"])
 def test_second_order_oracle_matches_finite_differences_of_the_first_order_oracle(name):
     rm = RobotModel.from_fixture(name)
     m = DuckRobot(rm)
@@ -38,7 +38,7 @@ def test_second_order_oracle_matches_finite_differences_of_the_first_order_oracl
             assert np.abs(a - b).max() <= 1e-7 * max(np.abs(b).max(), 1.0)
 
 
-@pytest.mark.parametrize("name", ["iiwa14", "arm6", "hyq", "tree12"])
+@pytest.mark.parametrize("name", ["iiwa14", "arm6", "hyq", "tree12", "atlas"])
 def test_fdsva_so_oracle_matches_finite_differences_of_the_first_order_oracle(name):
     from oracle.fdsva_so_oracle import fdsva_so
 
