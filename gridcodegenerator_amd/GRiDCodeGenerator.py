@@ -31,6 +31,10 @@ TUNING_DEFAULTS = {
     "stagger": 0,               # forward_dynamics_gradient kernel: waves in odd wave slots of their SIMD start k*64 cycles late (0 = off), so that the two
                                 # waves of a SIMD do not load, compute and store in lock-step
     "lds_pad": 0,               # occupancy experiment: extra elements per solve in the forward-dynamics-gradient slice of branch-frame robots
+    "stream_out": False,        # False | True | auto: forward_dynamics_gradient kernel of branch-frame robots stages ONE half of the record in LDS at a time
+                                # (d/dqd solved and stored after the factorisation, then d/dq); auto = where that raises the resident waves per CU.
+                                # Measured on the 30-DoF humanoid: 8 instead of 7 waves per CU, but 135 instead of 119 us per 16 384 solves (every wave
+                                # 25 % slower: the two column solves no longer interleave, spill reloads wait behind the mid-kernel stores) - off
     "fast_sincos": True,        # fp32 joint angles: branch-free Cody-Waite + minimax polynomials (29 instructions) instead of the math library's sincosf (120)
     "composite_scan": "f32",    # f32 | f64: precision of the suffix sums of the link inertias (tip/branch-frame paths); f64 = exact sums, rounded once
     "base_origin": "auto",      # auto | off | <joint position>: tip-frame path - the joint-space inertia entries of the base half of a chain are
@@ -96,12 +100,12 @@ class GRiDCodeGenerator:
         gen_inverse_dynamics_gradient_inner_function_call, gen_inverse_dynamics_gradient_inner, gen_dc_du_to_lds, gen_gradient_slots, gen_gradient_outputs_decl, \
         gen_inverse_dynamics_gradient_device, gen_inverse_dynamics_gradient_kernel, gen_inverse_dynamics_gradient_host, gen_inverse_dynamics_gradient, \
         gen_forward_dynamics_gradient_inner_temp_mem_size, gen_forward_dynamics_gradient_kernel_max_temp_mem_size, \
-        gen_forward_dynamics_gradient_inner_python, gen_forward_dynamics_gradient_device, gen_forward_dynamics_gradient_kernel, \
+        gen_forward_dynamics_gradient_inner_python, gen_forward_dynamics_gradient_device, gen_forward_dynamics_gradient_stream_device, gen_forward_dynamics_gradient_kernel, \
         gen_forward_dynamics_gradient_host, gen_forward_dynamics_gradient, gen_forward_dynamics_gradient_device_function_call, \
         gen_tip_frame_link_constants, gen_tip_frame_joint_offset, gen_tip_frame_library, gen_forward_dynamics_gradient_inner_tip, \
         gen_forward_dynamics_gradient_inner_tip_function_call, gen_tip_frame_gradient, \
         gen_inverse_dynamics_inner_tip, gen_inverse_dynamics_gradient_inner_tip, gen_forward_dynamics_inner_tip, gen_direct_minv_inner_tip, gen_tip_frame_components, \
-        gen_branch_frame_plan, gen_branch_frame_constants, gen_branch_frame_library, gen_branch_frame_components, gen_forward_dynamics_gradient_inner_branch, \
+        gen_branch_frame_plan, gen_branch_frame_constants, gen_branch_frame_library, gen_branch_frame_components, gen_forward_dynamics_gradient_inner_branch, gen_forward_dynamics_gradient_inner_branch_stream, \
         gen_forward_dynamics_gradient_inner_branch_function_call
 
     # NumPy debug helpers with the reference's names and signatures (reference GRiDCodeGenerator.py:50-51, README "Additional Features")
@@ -184,6 +188,7 @@ class GRiDCodeGenerator:
             self.tip_L = self.branch_plan["maxLb"]  # (length of the DPP scans)
         self.branch_tab_offset = 54 * n + (len(self.gen_tip_frame_link_constants()) if self.tip_frame else 0)
         self.branch_components = self.branch_frame and not self.tip_frame  # the stand-alone kernels of branched robots run the same path
+        self.fd_stream_out = False  # (decided in gen_lds_layout: it needs the slice size)
         self.reuse_rnea = self.register_walk and n <= 9 and self.tuning["fuse_fd"] and self.tuning["reuse_rnea"]  # measured: 16.6 us vs 15.0 us per launch with re-use (extra LDS traffic on the critical path), so off by default
         # tuning knob: minimum waves per SIMD the register allocator must leave room for (second __launch_bounds__ argument); 0 = compiler's choice
         self.min_waves_per_eu = int(self.tuning["min_waves"])
@@ -260,7 +265,8 @@ class GRiDCodeGenerator:
                                  "// general slice: same GRID_OFF_IN / GRID_OFF_X) and is best launched with FD_DU_SUGGESTED_THREADS threads per block",
                                  "const int FD_DU_LDS_PER_SOLVE = " + str(lds["FD_TOTAL"]) + ";",
                                  "const int FD_DU_OFF_SP = " + str(lds["FD_SP"]) + "; const int FD_DU_OFF_QDD = " + str(lds["FD_QDD"]) + ";",
-                                 "const int FD_DU_SUGGESTED_THREADS = " + str(fd_threads) + ";"])
+                                 "const int FD_DU_SUGGESTED_THREADS = " + str(fd_threads) + ";",
+                                 "const int FD_DU_OUT_PER_SOLVE = " + str(lds["FD_OUT_PER_SOLVE"]) + "; // staging of that kernel" + (": ONE half of the record at a time (d/dqd leaves after the factorisation, then d/dq: more resident waves per CU)" if self.fd_stream_out else "") + "; the _single_timing twin stages GRID_OUT_PER_SOLVE"])
         for k in ("ID", "MINV", "FD", "ABA", "ID_DU", "FD_DU"):
             self.gen_add_code_line("const int " + k + "_DYNAMIC_SHARED_MEM_COUNT = " + str(count) + ";")
         self.gen_add_code_lines(["const int ID_DU_MAX_SHARED_MEM_COUNT = " + str(count) + ";",
@@ -477,6 +483,8 @@ class GRiDCodeGenerator:
             self.gen_tip_frame_gradient(use_thread_group)
         if self.branch_frame:
             self.gen_forward_dynamics_gradient_inner_branch(use_thread_group)
+            if self.fd_stream_out:
+                self.gen_forward_dynamics_gradient_inner_branch_stream(use_thread_group)
         self.gen_forward_dynamics_gradient(use_thread_group)
         self.gen_idsva_so(use_thread_group)
         self.gen_fdsva_so(use_thread_group)

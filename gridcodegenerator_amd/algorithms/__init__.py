@@ -11,4 +11,4 @@ from ._tip_frame_gradient import gen_tip_frame_link_constants, gen_tip_frame_joi
     gen_forward_dynamics_gradient_inner_tip, gen_forward_dynamics_gradient_inner_tip_function_call, gen_tip_frame_gradient, \
     gen_inverse_dynamics_inner_tip, gen_inverse_dynamics_gradient_inner_tip, gen_forward_dynamics_inner_tip, gen_direct_minv_inner_tip, gen_tip_frame_components
 from ._branch_frame_gradient import gen_branch_frame_plan, gen_branch_frame_constants, gen_branch_frame_library, gen_branch_frame_components, \
-    gen_forward_dynamics_gradient_inner_branch, gen_forward_dynamics_gradient_inner_branch_function_call
+    gen_forward_dynamics_gradient_inner_branch, gen_forward_dynamics_gradient_inner_branch_stream, gen_forward_dynamics_gradient_inner_branch_function_call

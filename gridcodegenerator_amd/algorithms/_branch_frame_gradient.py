@@ -307,6 +307,12 @@ def gen_forward_dynamics_gradient_inner_branch(self, use_thread_group=False):
     _emit_branch_inner(self, "fdgrad", use_thread_group)
 
 
+def gen_forward_dynamics_gradient_inner_branch_stream(self, use_thread_group=False):
+    """The same inner for the forward_dynamics_gradient KERNEL where the LDS capacity of a CU bounds the resident waves (tuning stream_out,
+    decided in helpers/_topology_helpers.gen_lds_layout): one half of the record in LDS at a time, both halves stored from inside."""
+    _emit_branch_inner(self, "fdgrad_stream", use_thread_group)
+
+
 def gen_branch_frame_components(self, use_thread_group=False):
     """Stand-alone kernels of branched robots on the same path: subsets of the fused inner."""
     for mode in ("id", "idgrad", "fd", "minv"):
@@ -317,6 +323,8 @@ _BRANCH_MODES = {
     # mode: (function name, what it computes, leading parameters, their docs)
     "fdgrad": ("forward_dynamics_gradient_inner_branch", "Computes the gradient of forward dynamics",
                "T *s_df_du, const T *s_qd, const T *s_u, T *s_X, T *s_SP, T *s_qdd, const robotModel<T> *d_robotModel, const T gravity, const int lane"),
+    "fdgrad_stream": ("forward_dynamics_gradient_inner_branch_stream", "Computes the gradient of forward dynamics and streams it to global memory half by half",
+                      "T *d_df_du_k, T *s_df_du, const T *s_qd, const T *s_u, T *s_X, T *s_SP, T *s_qdd, const robotModel<T> *d_robotModel, const T gravity, const int lane"),
     "id": ("inverse_dynamics_inner_branch", "Compute the RNEA (Recursive Newton-Euler Algorithm)",
            "T *s_c, const T *s_qd, const T *s_qddin, T *s_X, T *s_SP, const robotModel<T> *d_robotModel, const T gravity, const int lane"),
     "idgrad": ("inverse_dynamics_gradient_inner_branch", "Computes the gradient of inverse dynamics",
@@ -330,11 +338,16 @@ _BRANCH_MODES = {
 
 def _emit_branch_inner(self, mode, use_thread_group=False):
     """One emitter for the five inners of the branch-frame path; `mode` selects the stages (see gen_branch_frame_components)."""
+    # "fdgrad_stream" (the forward-dynamics-gradient KERNEL of LDS-capacity-bound robots, gen_fd_stream_out): the image holds ONE half of the result
+    # (n^2 values) at a time - d/dqd is solved and stored right after the factorisation, then the same LDS takes d/dq: more resident waves per CU
+    stream = mode == "fdgrad_stream"
+    fname, fdoc, fsig = _BRANCH_MODES[mode]
+    if stream:
+        mode = "fdgrad"
     grad = mode in ("fdgrad", "idgrad")      # needs the Coriolis composites and the derivative entries
     kin = mode != "minv"                      # needs velocities / accelerations
     needs_M = mode in ("fdgrad", "fd", "minv")
     qdd_in = mode in ("id", "idgrad")        # joint accelerations are an input (id: the pointer may be null = zero)
-    fname, fdoc, fsig = _BRANCH_MODES[mode]
     m = self.model
     n = m.n
     P = self.branch_plan
@@ -344,7 +357,8 @@ def _emit_branch_inner(self, mode, use_thread_group=False):
     tab = self.branch_tab_offset
     H = 24
     A = self.gen_add_code_line
-    outdoc = {"fdgrad": "s_df_du receives -Minv*dc/du in the device layout [col*n + row] (2*NUM_JOINTS*NUM_JOINTS values; also the assembly area of dc/du)",
+    outdoc = {"fdgrad": "s_df_du receives -Minv*dc/du in the device layout [col*n + row] (2*NUM_JOINTS*NUM_JOINTS values; also the assembly area of dc/du)" if not stream else
+              "d_df_du_k is this solve's record in global memory (2*NUM_JOINTS*NUM_JOINTS values, layout [col*n + row]; nullptr: nothing is stored); s_df_du is LDS for ONE half of it (NUM_JOINTS*NUM_JOINTS values)",
               "id": "s_c receives the joint torques (lane of joint j writes s_c[j]); s_qddin may be nullptr (zero accelerations)",
               "idgrad": "s_dc_du receives dc/du in the device layout [col*n + row], col in [0,2n) = [d/dq | d/dqd]",
               "fd": "s_qdd receives the joint accelerations (it also holds tau - c on the way)",
@@ -360,7 +374,7 @@ def _emit_branch_inner(self, mode, use_thread_group=False):
     A("template <typename T>")
     A("__device__ __forceinline__")
     A("void %s(%s) {" % (fname, fsig), True)
-    ts_mode = mode == "fdgrad" and self.tuning["debug_stop"] == 20  # profiling build: per-wave cycle stamps at the phase boundaries replace the first outputs
+    ts_mode = mode == "fdgrad" and not stream and self.tuning["debug_stop"] == 20  # profiling build: per-wave cycle stamps at the phase boundaries replace the first outputs
 
     def TS(i):
         if ts_mode:
@@ -392,7 +406,7 @@ def _emit_branch_inner(self, mode, use_thread_group=False):
     for i in range(D):
         A("const int pc%d = static_cast<int>(d_L[%d]); const bool pv%d = pc%d >= 0; const int pj%d = pv%d ? (pc%d >> 2) : js; const bool act%d = pv%d && (%d >= own);"
           % (i, H + i, i, i, i, i, i, i, i, i))
-    zero = {"fdgrad": ("s_df_du", 2 * n * n), "idgrad": ("s_dc_du", 2 * n * n), "minv": ("s_Minv", n * ld)}.get(mode)
+    zero = {"fdgrad": ("s_df_du", n * n if stream else 2 * n * n), "idgrad": ("s_dc_du", 2 * n * n), "minv": ("s_Minv", n * ld)}.get(mode)
     A("grid_wave_sync();")
     spare_in_image = zero is not None and branch_spare_in_image(self, zero[1])
     lanes_head = (6 * D + 3) // 4 if spare_in_image else 0  # quads at the head of the image that take the spare path records of the frame chain
@@ -706,6 +720,7 @@ def _emit_branch_inner(self, mode, use_thread_group=False):
         _probe(self, "comp_BF", "BC:12", "fC:6")
     # ------------------------------------------------------------------ pass 1
     TS(4)
+    yo = 0 if stream else n  # column offset of the d/dqd half inside the image
     if mode == "fdgrad":
         A("// everything that does not depend on qdd: t1, t2, t4, tau - c; then the entries that couple this joint with its ancestors")
         A("T t1[6], t4[3];")
@@ -734,8 +749,8 @@ def _emit_branch_inner(self, mode, use_thread_group=False):
             A("const T lo_d = static_cast<T>(2)*grid_dot6(t1, Pdi) + t4[0]*Spi[0] + t4[1]*Spi[1] + t4[2]*Spi[2];")
             A("// (branch-free: lanes that have no such entry write to a spare word)")
             A("*(act%d ? &s_Mc[mstart + plen - %d] : s_trash) = %s; // (ancestors in ascending order, then the diagonal)" % (i, i + 1, "static_cast<T>(static_cast<float>(mkj))" if "M" in tuple(self.tuning.get("round_probe", ())) else "mkj"))
-            A("*(act%d ? &s_df_du[(%d + jid)*%d + pj%d] : s_trash) = up_d + ((own == %d) ? damping : Z); // + damping on the diagonal (oracle _test.py:486)" % (i, n, n, i, i))
-            A("*((act%d && own != %d) ? &s_df_du[(%d + pj%d)*%d + jid] : s_trash) = lo_d;" % (i, i, n, i, n))
+            A("*(act%d ? &s_df_du[(%d + jid)*%d + pj%d] : s_trash) = up_d + ((own == %d) ? damping : Z); // + damping on the diagonal (oracle _test.py:486)" % (i, yo, n, i, i))
+            A("*((act%d && own != %d) ? &s_df_du[(%d + pj%d)*%d + jid] : s_trash) = lo_d;" % (i, i, yo, i, n))
             walk_close()
         self.gen_add_end_control_flow()
     else:  # fd, minv: only the joint-space inertia, M[i][k] = S_i . (I^C_k S_k) for the ancestors-or-self i of this lane's joint k
@@ -842,6 +857,50 @@ def _emit_branch_inner(self, mode, use_thread_group=False):
             self.gen_add_end_control_flow()
         self.gen_add_end_function()
         return
+
+    def column_solves(cols):
+        """df/du = -M^-1 dc/du for the column(s) this lane owns: `cols` = [(register array, column offset in the image)]; the factors are read once per call."""
+        A("// df/du = -M^-1 dc/du for the column%s this lane owns (rows of its component; all other rows of the column are zero)" % ("s" if len(cols) > 1 else ""))
+        for si, sig in enumerate(shapes):
+            Nc = len(sig)
+            an = ancs[si]
+            midx = {}
+            for k in range(Nc):
+                for i in an[k] + [k]:
+                    midx[(i, k)] = len(midx)
+            A("%sif (shape == %d) {" % ("" if si == 0 else "else ", si), True)
+            A("T " + ", ".join("%s[%d]" % (v, Nc) for v, _ in cols) + ";")
+            A("#pragma unroll")
+            A("for (int i = 0; i < %d; i++) { " % Nc + " ".join("%s[i] = s_df_du[(%d + jid)*%d + cbase + i];" % (v, o, n) for v, o in cols) + " }")
+            for k in range(Nc - 1, 0, -1):
+                for i in an[k]:
+                    A("{ const T uu = s_Uc[%d]; " % midx[(i, k)] + " ".join("%s[%d] -= uu*%s[%d];" % (v, i, v, k) for v, _ in cols) + " }")
+            for k in range(Nc):
+                A("{ const T rr = s_Uc[%d]; " % midx[(k, k)] + " ".join("%s[%d] *= rr;" % (v, k) for v, _ in cols) + " }")
+            for k in range(1, Nc):
+                for i in an[k]:
+                    A("{ const T uu = s_Uc[%d]; " % midx[(i, k)] + " ".join("%s[%d] -= uu*%s[%d];" % (v, k, v, i) for v, _ in cols) + " }")
+            A("#pragma unroll")
+            A("for (int i = 0; i < %d; i++) { " % Nc + " ".join("s_df_du[(%d + jid)*%d + cbase + i] = -%s[i];" % (o, n, v) for v, o in cols) + " }")
+            self.gen_add_end_control_flow()
+
+    def store_half(dst_off, clear):
+        """stream form: the image (one half of the record, n^2 values) leaves with 16-byte stores of this lane group; then it is cleared for the other half."""
+        self.gen_add_sync(use_thread_group)
+        A("if (d_df_du_k != nullptr) {", True)
+        A("for (int e = 4*lane; e + 3 < %d; e += %d) { T tmp[4]; __builtin_memcpy(tmp, __builtin_assume_aligned(s_df_du + e, 4*sizeof(T) < 16 ? 4*sizeof(T) : 16), 4*sizeof(T)); grid_store4(d_df_du_k + %d + e, tmp); }" % (n * n, 4 * lanes, dst_off))
+        self.gen_add_end_control_flow()
+        if clear:
+            A("for (int e = lane; e < %d; e += %d) {" % (n * n // 4, lanes), True)
+            A("#pragma unroll")
+            A("for (int r = 0; r < 4; r++) { s_df_du[4*e + r] = Z; }")
+            self.gen_add_end_control_flow()
+            self.gen_add_sync(use_thread_group)
+
+    if stream:
+        A("// d/dqd half: solved and stored now, its LDS then takes the d/dq half")
+        column_solves([("y", 0)])
+        store_half(n * n, True)
     # ------------------------------------------------------------------ pass 2
     TS(6)
     A("// the acceleration-dependent parts: a += sum over the ancestors of S_i qdd_i, f^C += sum over the subtree of I_k da_k")
@@ -898,29 +957,11 @@ def _emit_branch_inner(self, mode, use_thread_group=False):
     self.gen_add_sync(use_thread_group)
     # ------------------------------------------------------------------ column solves
     TS(7)
-    A("// df/du = -M^-1 dc/du for the two columns this lane owns (rows of its component; all other rows of the column are zero)")
-    for si, sig in enumerate(shapes):
-        Nc = len(sig)
-        an = ancs[si]
-        midx = {}
-        for k in range(Nc):
-            for i in an[k] + [k]:
-                midx[(i, k)] = len(midx)
-        A("%sif (shape == %d) {" % ("" if si == 0 else "else ", si), True)
-        A("T x[%d], y[%d];" % (Nc, Nc))
-        A("#pragma unroll")
-        A("for (int i = 0; i < %d; i++) { x[i] = s_df_du[jid*%d + cbase + i]; y[i] = s_df_du[(%d + jid)*%d + cbase + i]; }" % (Nc, n, n, n))
-        for k in range(Nc - 1, 0, -1):
-            for i in an[k]:
-                A("{ const T uu = s_Uc[%d]; x[%d] -= uu*x[%d]; y[%d] -= uu*y[%d]; }" % (midx[(i, k)], i, k, i, k))
-        for k in range(Nc):
-            A("{ const T rr = s_Uc[%d]; x[%d] *= rr; y[%d] *= rr; }" % (midx[(k, k)], k, k))
-        for k in range(1, Nc):
-            for i in an[k]:
-                A("{ const T uu = s_Uc[%d]; x[%d] -= uu*x[%d]; y[%d] -= uu*y[%d]; }" % (midx[(i, k)], k, i, k, i))
-        A("#pragma unroll")
-        A("for (int i = 0; i < %d; i++) { s_df_du[jid*%d + cbase + i] = -x[i]; s_df_du[(%d + jid)*%d + cbase + i] = -y[i]; }" % (Nc, n, n, n))
-        self.gen_add_end_control_flow()
+    if stream:
+        column_solves([("x", 0)])
+        store_half(0, False)
+    else:
+        column_solves([("x", 0), ("y", n)])
     if ts_mode:
         self.gen_add_sync(use_thread_group)
         TS(8)

@@ -111,8 +111,30 @@ def gen_forward_dynamics_gradient_device(self, use_thread_group=False, use_qdd_M
     self.gen_add_end_function()
 
 
+def gen_forward_dynamics_gradient_stream_device(self, use_thread_group=False):
+    """Device function behind the forward_dynamics_gradient kernel where gen_lds_layout chose the streamed output (self.fd_stream_out)."""
+    n = self.model.n
+    self.gen_add_func_doc("Computes the gradient of forward dynamics and stores it to global memory half by half (lane-group cooperative; the kernel's form where LDS capacity bounds the resident waves)",
+                          ["d/dqd (columns n..2n-1) leaves right after the factorisation, d/dq (columns 0..n-1) at the end; all lanes of the solve's lane group must call it"],
+                          ["d_df_du_k is this solve's record in global memory, 2*NUM_JOINTS*NUM_JOINTS values [col*n + row] (nullptr: lane group without a solve, nothing is stored)",
+                           "s_half is LDS for one half of the record: NUM_JOINTS*NUM_JOINTS = " + str(n * n) + " values",
+                           "s_q is the vector of joint positions", "s_qd is the vector of joint velocities", "s_u is the vector of input torques",
+                           "s_work is this solve's LDS workspace of FD_DU_LDS_PER_SOLVE elements",
+                           "d_robotModel is the pointer to the initialized model specific helpers on the GPU (XImats, topology_helpers, etc.)",
+                           "gravity is the gravity constant", "lane is the caller's lane index inside the solve's lane group"], None)
+    self.gen_add_code_line("template <typename T>")
+    self.gen_add_code_line("__device__ __forceinline__")
+    self.gen_add_code_line("void forward_dynamics_gradient_stream_device(T *d_df_du_k, T *s_half, const T *s_q, const T *s_qd, const T *s_u, T *s_work, const robotModel<T> *d_robotModel, const T gravity, const int lane) {", True)
+    self.gen_add_code_line("T *s_X = &s_work[GRID_OFF_X]; T *s_SP = &s_work[FD_DU_OFF_SP]; T *s_qdd = &s_work[FD_DU_OFF_QDD];")
+    self.gen_load_update_XImats_helpers_function_call(use_thread_group)
+    self.gen_add_code_line("forward_dynamics_gradient_inner_branch_stream<T>(d_df_du_k, s_half, s_qd, s_u, s_X, s_SP, s_qdd, d_robotModel, gravity, lane);")
+    self.gen_add_sync(use_thread_group)
+    self.gen_add_end_function()
+
+
 def gen_forward_dynamics_gradient_kernel(self, use_thread_group=False, use_qdd_Minv_input=False, single_call_timing=False):
     n = self.model.n
+    stream = getattr(self, "fd_stream_out", False) and not use_qdd_Minv_input and not single_call_timing
     func_params = ["d_df_du is a pointer to memory for the final result of size 2*NUM_JOINTS*NUM_JOINTS = " + str(2 * n * n),
                    "d_q_dq is the vector of joint positions and velocities", "stride_q_qd is the stride between each q, qd",
                    "d_robotModel is the pointer to the initialized model specific helpers on the GPU (XImats, topology_helpers, etc.)",
@@ -147,7 +169,7 @@ def gen_forward_dynamics_gradient_kernel(self, use_thread_group=False, use_qdd_M
     else:
         self.gen_add_code_line("T *s_q_qd_u = &s_mem[GRID_OFF_IN]; T *s_q = s_q_qd_u; T *s_qd = &s_q_qd_u[%d]; T *s_u = &s_q_qd_u[%d]; T *s_qdd = &s_mem[%s];" % (n, 2 * n, "FD_DU_OFF_QDD" if getattr(self, "branch_frame", False) else "GRID_OFF_QDD"))
     if getattr(self, "branch_frame", False) and not use_qdd_Minv_input:
-        self.gen_add_code_line("T *s_df_du = &s_out_all[grp*%d]; (void)s_qdd;" % (n * n if self.tuning["out_half"] else 2 * n * n))
+        self.gen_add_code_line("T *s_df_du = &s_out_all[grp*%d]; (void)s_qdd;%s" % (n * n if (self.tuning["out_half"] or stream) else 2 * n * n, " // ONE half of this solve's record at a time" if stream else ""))
     else:
         self.gen_add_code_line("T *s_Minv = &s_mem[GRID_OFF_MINV]; T *s_df_du = &s_out_all[grp*%d]; (void)s_Minv; (void)s_qdd;" % (2 * n * n))
     if single_call_timing:
@@ -163,7 +185,10 @@ def gen_forward_dynamics_gradient_kernel(self, use_thread_group=False, use_qdd_M
         self.gen_add_code_line("// compute with NUM_TIMESTEPS as NUM_REPS for timing")
         self.gen_add_code_line("for (int rep = 0; rep < NUM_TIMESTEPS; rep++){", True)
     self.gen_add_code_line("// compute")
-    self.gen_forward_dynamics_gradient_device_function_call(compute_Minv=use_qdd_Minv_input)
+    if stream:
+        self.gen_add_code_line("forward_dynamics_gradient_stream_device<T>(valid ? &d_df_du[static_cast<size_t>(kc)*%d] : nullptr, s_df_du, s_q, s_qd, s_u, s_mem, d_robotModel, gravity, lane); // (stores both halves itself)" % (2 * n * n))
+    else:
+        self.gen_forward_dynamics_gradient_device_function_call(compute_Minv=use_qdd_Minv_input)
     if self.DEBUG_MODE and not single_call_timing:
         # the reference's DEBUG_MODE prints the same-named intermediates of its NumPy oracle (reference _forward_dynamics_gradient.py:28-46)
         self.gen_add_debug_print_code_lines(["printf(\"Minv\\n\");", "printMat<T,%d,%d>(s_Minv,GRID_MINV_LD);" % (n, n),
@@ -174,7 +199,7 @@ def gen_forward_dynamics_gradient_kernel(self, use_thread_group=False, use_qdd_M
         self.gen_add_end_control_flow()
     if single_call_timing:
         self.gen_kernel_save_result_single_timing("df_du", 2 * n * n, use_thread_group)
-    else:
+    elif not stream:
         self.gen_kernel_save_result("df_du", 2 * n * n, 2 * n * n, use_thread_group)
     if not single_call_timing:
         self.gen_add_end_control_flow()
@@ -210,7 +235,7 @@ def gen_forward_dynamics_gradient_host(self, mode=0):
     if single_call_timing:
         self.gen_add_code_line("struct timespec start, end; clock_gettime(CLOCK_MONOTONIC,&start);")
     self.gen_add_code_lines(["if (USE_QDD_MINV_FLAG) {hipLaunchKernelGGL((" + kern + "),block_dimms,thread_dimms,grid_lds_bytes<T>(thread_dimms),0,hd_data->d_df_du,hd_data->d_q_qd_u,stride_q_qd,hd_data->d_qdd,hd_data->d_Minv,d_robotModel,gravity,num_timesteps);}",
-                             "else {hipLaunchKernelGGL((" + kern + "),block_dimms,thread_dimms,grid_lds_bytes<T>(thread_dimms, FD_DU_LDS_PER_SOLVE),0,hd_data->d_df_du,hd_data->d_q_qd_u,stride_q_qd,d_robotModel,gravity,num_timesteps);}",
+                             "else {hipLaunchKernelGGL((" + kern + "),block_dimms,thread_dimms,grid_lds_bytes<T>(thread_dimms, FD_DU_LDS_PER_SOLVE" + ("" if single_call_timing else ", FD_DU_OUT_PER_SOLVE") + "),0,hd_data->d_df_du,hd_data->d_q_qd_u,stride_q_qd,d_robotModel,gravity,num_timesteps);}",
                              "gpuErrchk(hipGetLastError()); gpuErrchk(hipDeviceSynchronize());"])
     if single_call_timing:
         self.gen_add_code_line("clock_gettime(CLOCK_MONOTONIC,&end);")
@@ -234,6 +259,8 @@ def gen_forward_dynamics_gradient(self, use_thread_group=False):
     # first device wrappers
     self.gen_forward_dynamics_gradient_device(use_thread_group, False)
     self.gen_forward_dynamics_gradient_device(use_thread_group, True)
+    if getattr(self, "fd_stream_out", False):
+        self.gen_forward_dynamics_gradient_stream_device(use_thread_group)
     # then kernels
     self.gen_forward_dynamics_gradient_kernel(use_thread_group, True, True)
     self.gen_forward_dynamics_gradient_kernel(use_thread_group, True, False)

@@ -187,7 +187,7 @@ static int fd_grad_device(grid_handle *h, const T *d_q_qd_u, int stride, int N, 
     if ((rc = ensure_typed<T>(h))) return rc;
     launch_cfg c;
     // this kernel has its own (smaller) LDS slice and suggested block size: FD_DU_LDS_PER_SOLVE, FD_DU_SUGGESTED_THREADS
-    if ((rc = make_launch<T>(h, N, grid::FD_DU_SUGGESTED_THREADS, grid::GRID_MAX_SOLVES_PER_BLOCK, grid::FD_DU_LDS_PER_SOLVE, grid::GRID_OUT_PER_SOLVE, &c))) return rc;
+    if ((rc = make_launch<T>(h, N, grid::FD_DU_SUGGESTED_THREADS, grid::GRID_MAX_SOLVES_PER_BLOCK, grid::FD_DU_LDS_PER_SOLVE, grid::FD_DU_OUT_PER_SOLVE, &c))) return rc;
     hipLaunchKernelGGL((grid::forward_dynamics_gradient_kernel<T>), c.grid, c.block, c.lds, (hipStream_t)stream, d_df_du, d_q_qd_u, stride,
                        typed<T>(h).d_robotModel, gravity, N);
     GRID_TRY(hipGetLastError());

@@ -68,6 +68,17 @@ def gen_lds_layout(self):
             off["TOTAL"] = cur = tot + (4 if ((tot // 4) % 2 == 0) else 0)
         off["FD_TOTAL"] = tot
     off["OUT_PER_SOLVE"] = _pad4(n * n if self.tuning["out_half"] else 2 * n * n)  # output staging, kept behind all slices (contiguous across the lane groups of a wave)
+    # forward_dynamics_gradient kernel of LDS-capacity-bound branch-frame robots: stage one half of the record at a time if that makes more waves
+    # resident on a CU (160 KB, allocation granule 512 B, at most 8 waves at 256 VGPRs)
+    off["FD_OUT_PER_SOLVE"] = off["OUT_PER_SOLVE"]
+    want = self.tuning["stream_out"]
+    self.fd_stream_out = False
+    if getattr(self, "branch_frame", False) and want is not False and (n * n) % 4 == 0 and int(self.tuning["debug_stop"]) == 0 and not self.tuning["out_half"]:
+        spw = 64 // self.lanes_per_solve
+        waves = lambda out: min(8, (160 * 1024) // (-(-(spw * (off["FD_TOTAL"] + out) * 4) // 512) * 512))
+        if want is True or (off["FD_TOTAL"] < off["TOTAL"] and waves(n * n) > waves(off["OUT_PER_SOLVE"])):
+            self.fd_stream_out = True
+            off["FD_OUT_PER_SOLVE"] = n * n
     return off
 
 
