@@ -35,6 +35,8 @@ TUNING_DEFAULTS = {
                                 # (d/dqd solved and stored after the factorisation, then d/dq); auto = where that raises the resident waves per CU.
                                 # Measured on the 30-DoF humanoid: 8 instead of 7 waves per CU, but 135 instead of 119 us per 16 384 solves (every wave
                                 # 25 % slower: the two column solves no longer interleave, spill reloads wait behind the mid-kernel stores) - off
+    "factor_split": "auto",     # auto | branch | component: who eliminates which pivots of the tree-sparse factorisation on the branch-frame path
+                                # (algorithms/_branch_frame_gradient.py: branch_factor_by_branch)
     "fast_sincos": True,        # fp32 joint angles: branch-free Cody-Waite + minimax polynomials (29 instructions) instead of the math library's sincosf (120)
     "composite_scan": "f32",    # f32 | f64: precision of the suffix sums of the link inertias (tip/branch-frame paths); f64 = exact sums, rounded once
     "base_origin": "auto",      # auto | off | <joint position>: tip-frame path - the joint-space inertia entries of the base half of a chain are

@@ -137,6 +137,119 @@ def branch_spare_in_image(self, image_len):
     return image_len >= 6 * D and (6 * D + 3) // 4 <= self.lanes_per_solve
 
 
+def branch_factor_by_branch(self):
+    """tuning factor_split: "branch" = every branch eliminates its own pivots (lanes of different branches work in parallel, tree level by tree
+    level, Schur complements onto the ancestors handed up through the 28-value branch records); "component" = every lane factors its whole
+    base-rooted component.  auto = branch where the hand-over fits the records (a0 (a0 + 3) / 2 <= 28 values, a0 = ancestors above the branch)
+    and the split removes at least a quarter of the multiply-adds a wave executes."""
+    want = self.tuning["factor_split"]
+    P, m = self.branch_plan, self.model
+    a0 = lambda b: len(P["paths"][b]) - len(P["branches"][b])
+    fits = all(a0(b) * (a0(b) + 3) // 2 <= 28 for b in range(P["nb"]))
+    if want == "branch" and not fits:
+        raise NotImplementedError("factor_split=branch: a branch of this robot has more than 6 ancestors above it (the hand-over record holds 28 values)")
+    if want != "auto":
+        return want == "branch"
+    # multiply-adds one wave executes (all code paths of a wave run, exec-masked): one block per component shape against one block per
+    # (level, branch length, path length).  Measured, 16 384 solves: 30-DoF humanoid 367 -> 206, 109.6 -> 97.3 us (and no scratch any more);
+    # 12-DoF tree 65 -> 64 with two more hand-over levels, 31.1 -> 33.1 us
+    tri = lambda k: k * (k + 1) // 2
+    shape_work = {}
+    for j in range(m.n):
+        sh = P["shape_of"][P["comp_base"][j]]
+        shape_work.setdefault(sh, {}).setdefault(P["comp_base"][j], 0)
+        shape_work[sh][P["comp_base"][j]] += tri(len(m.ancestors[j]))
+    by_component = sum(max(w.values()) for w in shape_work.values())
+    by_branch = sum({(P["level"][b], len(P["branches"][b]), len(P["paths"][b])): sum(tri(k) for k in range(a0(b), len(P["paths"][b]))) for b in range(P["nb"])}.values())
+    return fits and 4 * by_branch <= 3 * by_component
+
+
+def _emit_factor_by_branch(self, P, with_rhs, R32, use_thread_group, ptr):
+    """Tree-sparse U D U^T, distributed over the branches (see branch_factor_by_branch).  Path positions d = 0 .. plen-1 count from the component's
+    root; a branch of Lb joints below a0 = plen - Lb ancestors owns the columns d >= a0 of the triangle W[i][j], i <= j < plen."""
+    A = self.gen_add_code_line
+    nb, branches, paths, level, kids = P["nb"], P["branches"], P["paths"], P["level"], P["kids"]
+    maxlevel, maxchild, maxLb = P["maxlevel"], P["maxchild"], P["maxLb"]
+    tri = lambda i, j: j * (j + 1) // 2 + i  # packed index of (i <= j) in a hand-over record
+    A("// tree-sparse U D U^T of the joint-space inertia, leaves first (no fill-in), distributed over the branches: the lanes of a branch eliminate the")
+    A("// pivots of their own joints (replicated inside the branch only), tree level by tree level; the Schur complement onto the ancestors and the")
+    A("// forward-substituted right-hand side travel to the parent branch through the branch records; the first lane of a branch parks its factors")
+    A("T *s_Ub = %s, *s_Mb = %s; // (absolute: column of joint j starts at mstart(j))" % (ptr("U"), ptr("M")))
+    A("const int a0 = plen - Lb, mb0 = mstart - pos*a0 - (pos*(pos + 1))/2, jid0 = jid - pos; // ancestors above the branch, column start and id of the branch's first joint")
+    A("(void)a0; (void)mb0; (void)jid0; (void)ubase; (void)li; (void)cbase; (void)shape;")
+    if with_rhs:
+        A("T bk[%d]; // forward-substituted right-hand side of this branch's joints" % maxLb)
+        A("#pragma unroll")
+        A("for (int r = 0; r < %d; r++) { bk[r] = Z; }" % maxLb)
+    sigs = {}
+    for b in range(nb):
+        sigs.setdefault(level[b], {}).setdefault((len(branches[b]), len(paths[b])), []).append(b)
+    col0 = lambda a0_, t: sum(a0_ + s_ + 1 for s_ in range(t))  # offset of the column of the branch's joint t behind mb0
+    for lv in range(maxlevel, -1, -1):
+        first = True
+        for (Lb_, pl), bs in sorted(sigs.get(lv, {}).items()):
+            a0_ = pl - Lb_
+            A("%sif (level == %d && Lb == %d && plen == %d) { // branches of %d joints below %d ancestors" % ("" if first else "else ", lv, Lb_, pl, Lb_, a0_), True)
+            first = False
+            for t in range(Lb_):
+                k = a0_ + t
+                A(" ".join("T W%d_%d = s_Mb[mb0 + %d];" % (i, k, col0(a0_, t) + i) for i in range(k + 1)))
+            if a0_:
+                A("T " + ", ".join("W%d_%d = Z" % (i, j) for j in range(a0_) for i in range(j + 1)) + "; // Schur complement onto the ancestors")
+            if with_rhs:
+                if a0_:
+                    A("T " + ", ".join("b%d = Z" % d for d in range(a0_)) + ";")
+                A(" ".join("T b%d = s_qdd[jid0 + %d];" % (a0_ + t, t) for t in range(Lb_)))
+            if any(kids[b] for b in bs):
+                for c in range(maxchild):
+                    A("if (cs%d >= 0) { const T *g = &s_G[28*cs%d]; // what child branch %d leaves for its ancestors" % (c, c, c), True)
+                    A(" ".join("W%d_%d += g[%d];" % (i, j, tri(i, j)) for j in range(pl) for i in range(j + 1)))
+                    if with_rhs:
+                        A(" ".join("b%d += g[%d];" % (d, pl * (pl + 1) // 2 + d) for d in range(pl)))
+                    self.gen_add_end_control_flow()
+            for k in range(pl - 1, a0_ - 1, -1):
+                A("const T rd%d = %s;" % (k, R32("grid_rcp(W%d_%d)" % (k, k))))
+                if k:
+                    A(" ".join("const T U%d_%d = %s;" % (i, k, R32("W%d_%d*rd%d" % (i, k, k))) for i in range(k)))
+                    for j in range(k):
+                        A(" ".join("W%d_%d -= U%d_%d*W%d_%d;" % (i, j, i, k, j, k) for i in range(j + 1)))
+                    if with_rhs:
+                        A(" ".join("b%d -= U%d_%d*b%d;" % (i, i, k, k) for i in range(k)))
+                if with_rhs:
+                    A("b%d *= rd%d;" % (k, k))
+            if with_rhs:
+                A(" ".join("bk[%d] = b%d;" % (t, a0_ + t) for t in range(Lb_)))
+            A("if (pos == 0) { // the first lane of the branch parks the factors%s" % (" and posts the hand-over" if a0_ else ""), True)
+            for t in range(Lb_):
+                k = a0_ + t
+                A(" ".join(["s_Ub[mb0 + %d] = U%d_%d;" % (col0(a0_, t) + i, i, k) for i in range(k)] + ["s_Ub[mb0 + %d] = rd%d;" % (col0(a0_, t) + k, k)]))
+            if a0_:
+                A("T *g = &s_G[28*slot];")
+                A(" ".join("g[%d] = W%d_%d;" % (tri(i, j), i, j) for j in range(a0_) for i in range(j + 1)))
+                if with_rhs:
+                    A(" ".join("g[%d] = b%d;" % (a0_ * (a0_ + 1) // 2 + d, d) for d in range(a0_)))
+            self.gen_add_end_control_flow()
+            self.gen_add_end_control_flow()
+        self.gen_add_sync(use_thread_group)
+    if not with_rhs:
+        return
+    A("// back substitution, root branches first: qdd of the ancestors comes back through s_qdd, the factors from where they were parked")
+    for lv in range(0, maxlevel + 1):
+        first = True
+        for (Lb_, pl), bs in sorted(sigs.get(lv, {}).items()):
+            a0_ = pl - Lb_
+            A("%sif (level == %d && Lb == %d && plen == %d) {" % ("" if first else "else ", lv, Lb_, pl), True)
+            first = False
+            if a0_:
+                A(" ".join("const T x%d = s_qdd[pj%d];" % (d, pl - 1 - d) for d in range(a0_)))
+            for t in range(Lb_):
+                k = a0_ + t
+                A("const T x%d = bk[%d]%s;" % (k, t, "".join(" - s_Ub[mb0 + %d]*x%d" % (col0(a0_, t) + i, i) for i in range(k))))
+            A("if (pos == 0) { " + " ".join("s_qdd[jid0 + %d] = x%d;" % (t, a0_ + t) for t in range(Lb_)) + " }")
+            self.gen_add_end_control_flow()
+        self.gen_add_sync(use_thread_group)
+
+
 def gen_branch_frame_constants(self):
     """Table rows appended to grid_model_constants: one row per lane
     [Ic (6) | c (3) | m | damping | axis | joint id | pos | branch length | level | branch slot | component base | shape | path length | factor base of the component | start of the joint's column in the compact M | path step of the branch's base-origin joint (-1: none) | 1 if this lane's column of M uses the base family |
@@ -780,54 +893,61 @@ def _emit_branch_inner(self, mode, use_thread_group=False):
     shapes = P["shapes"]
     NCmax = max(len(s_) for s_ in shapes)
     ancs = [_anc_local(s_) for s_ in shapes]
-    A("// tree-sparse U D U^T of the joint-space inertia of this lane's component (leaves first: no fill-in), wave-uniform inside the component,")
-    A("// fused with the forward substitution of tau - c; the first lane of the component parks the factors in the (now free) X(q) storage")
     with_rhs = mode in ("fdgrad", "fd")
     park = mode in ("fdgrad", "minv")
-    if with_rhs:
-        A("T bq[%d];" % NCmax)
-    for si, sig in enumerate(shapes):
-        Nc = len(sig)
-        an = ancs[si]
-        midx = {}
-        for k in range(Nc):
-            for i in an[k] + [k]:
-                midx[(i, k)] = len(midx)
-        A("%sif (shape == %d) { // component of %d joints" % ("" if si == 0 else "else ", si, Nc), True)
-        for k in range(Nc):
-            A(" ".join("T A%d_%d = s_Mc[ubase + %d];" % (i, k, midx[(i, k)]) for i in an[k] + [k]))
+    R32 = (lambda e: "static_cast<T>(static_cast<float>(%s))" % e) if "factor" in tuple(self.tuning.get("round_probe", ())) else (lambda e: e)
+    by_branch = branch_factor_by_branch(self)
+    if by_branch:
+        _emit_factor_by_branch(self, P, with_rhs, R32, use_thread_group, ptr)
+    else:
+        A("// tree-sparse U D U^T of the joint-space inertia of this lane's component (leaves first: no fill-in), wave-uniform inside the component,")
+        A("// fused with the forward substitution of tau - c; the first lane of the component parks the factors in the (now free) X(q) storage")
+        with_rhs = mode in ("fdgrad", "fd")
+        park = mode in ("fdgrad", "minv")
         if with_rhs:
-            A("#pragma unroll")
-            A("for (int i = 0; i < %d; i++) { bq[i] = s_qdd[cbase + i]; }" % Nc)
-        for k in range(Nc - 1, -1, -1):
-            R32 = (lambda e: "static_cast<T>(static_cast<float>(%s))" % e) if "factor" in tuple(self.tuning.get("round_probe", ())) else (lambda e: e)
-            A("const T rd%d = %s;" % (k, R32("grid_rcp(A%d_%d)" % (k, k))))
-            if an[k]:
-                A(" ".join("const T U%d_%d = %s;" % (i, k, R32("A%d_%d*rd%d" % (i, k, k))) for i in an[k]))
-                for j in an[k]:
-                    A(" ".join("A%d_%d -= U%d_%d*A%d_%d;" % (i, j, i, k, j, k) for i in an[k] if i <= j))
-                if with_rhs:
-                    A(" ".join("bq[%d] -= U%d_%d*bq[%d];" % (i, i, k, k) for i in an[k]))
-            if with_rhs:
-                A("bq[%d] *= rd%d;" % (k, k))
-        if with_rhs:
-            for k in range(1, Nc):
-                if an[k]:
-                    A("bq[%d] -= %s;" % (k, " + ".join("U%d_%d*bq[%d]" % (i, k, i) for i in an[k])))
-        if park:
-            A("if (li == 0) { // the first lane of the component parks the factors", True)
-            for k in range(Nc):
-                A(" ".join(["s_Uc[%d] = U%d_%d;" % (midx[(i, k)], i, k) for i in an[k]] + ["s_Uc[%d] = rd%d;" % (midx[(k, k)], k)]))
-            self.gen_add_end_control_flow()
-        self.gen_add_end_control_flow()
-    self.gen_add_sync(use_thread_group)  # every lane has read tau - c
-    if with_rhs:
+            A("T bq[%d];" % NCmax)
         for si, sig in enumerate(shapes):
-            A("%sif (shape == %d && li == 0) {" % ("" if si == 0 else "else ", si), True)
-            A("#pragma unroll")
-            A("for (int i = 0; i < %d; i++) { s_qdd[cbase + i] = bq[i]; }" % len(sig))
+            Nc = len(sig)
+            an = ancs[si]
+            midx = {}
+            for k in range(Nc):
+                for i in an[k] + [k]:
+                    midx[(i, k)] = len(midx)
+            A("%sif (shape == %d) { // component of %d joints" % ("" if si == 0 else "else ", si, Nc), True)
+            for k in range(Nc):
+                A(" ".join("T A%d_%d = s_Mc[ubase + %d];" % (i, k, midx[(i, k)]) for i in an[k] + [k]))
+            if with_rhs:
+                A("#pragma unroll")
+                A("for (int i = 0; i < %d; i++) { bq[i] = s_qdd[cbase + i]; }" % Nc)
+            for k in range(Nc - 1, -1, -1):
+                R32 = (lambda e: "static_cast<T>(static_cast<float>(%s))" % e) if "factor" in tuple(self.tuning.get("round_probe", ())) else (lambda e: e)
+                A("const T rd%d = %s;" % (k, R32("grid_rcp(A%d_%d)" % (k, k))))
+                if an[k]:
+                    A(" ".join("const T U%d_%d = %s;" % (i, k, R32("A%d_%d*rd%d" % (i, k, k))) for i in an[k]))
+                    for j in an[k]:
+                        A(" ".join("A%d_%d -= U%d_%d*A%d_%d;" % (i, j, i, k, j, k) for i in an[k] if i <= j))
+                    if with_rhs:
+                        A(" ".join("bq[%d] -= U%d_%d*bq[%d];" % (i, i, k, k) for i in an[k]))
+                if with_rhs:
+                    A("bq[%d] *= rd%d;" % (k, k))
+            if with_rhs:
+                for k in range(1, Nc):
+                    if an[k]:
+                        A("bq[%d] -= %s;" % (k, " + ".join("U%d_%d*bq[%d]" % (i, k, i) for i in an[k])))
+            if park:
+                A("if (li == 0) { // the first lane of the component parks the factors", True)
+                for k in range(Nc):
+                    A(" ".join(["s_Uc[%d] = U%d_%d;" % (midx[(i, k)], i, k) for i in an[k]] + ["s_Uc[%d] = rd%d;" % (midx[(k, k)], k)]))
+                self.gen_add_end_control_flow()
             self.gen_add_end_control_flow()
-        self.gen_add_sync(use_thread_group)
+        self.gen_add_sync(use_thread_group)  # every lane has read tau - c
+        if with_rhs:
+            for si, sig in enumerate(shapes):
+                A("%sif (shape == %d && li == 0) {" % ("" if si == 0 else "else ", si), True)
+                A("#pragma unroll")
+                A("for (int i = 0; i < %d; i++) { s_qdd[cbase + i] = bq[i]; }" % len(sig))
+                self.gen_add_end_control_flow()
+            self.gen_add_sync(use_thread_group)
     if mode == "fd":
         self.gen_add_end_function()
         return
