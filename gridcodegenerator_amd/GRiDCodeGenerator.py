@@ -31,10 +31,9 @@ TUNING_DEFAULTS = {
     "stagger": 0,               # forward_dynamics_gradient kernel: waves in odd wave slots of their SIMD start k*64 cycles late (0 = off), so that the two
                                 # waves of a SIMD do not load, compute and store in lock-step
     "lds_pad": 0,               # occupancy experiment: extra elements per solve in the forward-dynamics-gradient slice of branch-frame robots
-    "stream_out": False,        # False | True | auto: forward_dynamics_gradient kernel of branch-frame robots stages ONE half of the record in LDS at a time
-                                # (d/dqd solved and stored after the factorisation, then d/dq); auto = where that raises the resident waves per CU.
-                                # Measured on the 30-DoF humanoid: 8 instead of 7 waves per CU, but 135 instead of 119 us per 16 384 solves (every wave
-                                # 25 % slower: the two column solves no longer interleave, spill reloads wait behind the mid-kernel stores) - off
+    "stream_out": "auto",       # auto | True | False: forward_dynamics_gradient kernel of branch-frame robots stages ONE half of the record in LDS at a time
+                                # (dc/dqd columns parked compactly while dc/dq is assembled, both solved together, stored half after half);
+                                # auto = where that raises the resident waves per CU (the 30-DoF humanoid: 7 -> 8)
     "factor_split": "auto",     # auto | branch | component: who eliminates which pivots of the tree-sparse factorisation on the branch-frame path
                                 # (algorithms/_branch_frame_gradient.py: branch_factor_by_branch)
     "fast_sincos": True,        # fp32 joint angles: branch-free Cody-Waite + minimax polynomials (29 instructions) instead of the math library's sincosf (120)
@@ -266,7 +265,7 @@ class GRiDCodeGenerator:
         self.gen_add_code_lines(["// the forward_dynamics_gradient kernel with (q, qd, u) input carves slices of FD_DU_LDS_PER_SOLVE elements (a prefix-compatible subset of the",
                                  "// general slice: same GRID_OFF_IN / GRID_OFF_X) and is best launched with FD_DU_SUGGESTED_THREADS threads per block",
                                  "const int FD_DU_LDS_PER_SOLVE = " + str(lds["FD_TOTAL"]) + ";",
-                                 "const int FD_DU_OFF_SP = " + str(lds["FD_SP"]) + "; const int FD_DU_OFF_QDD = " + str(lds["FD_QDD"]) + ";",
+                                 "const int FD_DU_OFF_SP = " + str(lds["FD_SP"]) + "; const int FD_DU_OFF_QDD = " + str(lds["FD_QDD"]) + "; const int FD_DU_OFF_YPARK = " + str(lds["FD_YPARK"]) + ";",
                                  "const int FD_DU_SUGGESTED_THREADS = " + str(fd_threads) + ";",
                                  "const int FD_DU_OUT_PER_SOLVE = " + str(lds["FD_OUT_PER_SOLVE"]) + "; // staging of that kernel" + (": ONE half of the record at a time (d/dqd leaves after the factorisation, then d/dq: more resident waves per CU)" if self.fd_stream_out else "") + "; the _single_timing twin stages GRID_OUT_PER_SOLVE"])
         for k in ("ID", "MINV", "FD", "ABA", "ID_DU", "FD_DU"):

@@ -436,8 +436,8 @@ _BRANCH_MODES = {
     # mode: (function name, what it computes, leading parameters, their docs)
     "fdgrad": ("forward_dynamics_gradient_inner_branch", "Computes the gradient of forward dynamics",
                "T *s_df_du, const T *s_qd, const T *s_u, T *s_X, T *s_SP, T *s_qdd, const robotModel<T> *d_robotModel, const T gravity, const int lane"),
-    "fdgrad_stream": ("forward_dynamics_gradient_inner_branch_stream", "Computes the gradient of forward dynamics and streams it to global memory half by half",
-                      "T *d_df_du_k, T *s_df_du, const T *s_qd, const T *s_u, T *s_X, T *s_SP, T *s_qdd, const robotModel<T> *d_robotModel, const T gravity, const int lane"),
+    "fdgrad_stream": ("forward_dynamics_gradient_inner_branch_stream", "Computes the gradient of forward dynamics with ONE half of the record staged in LDS at a time and stores both halves to global memory",
+                      "T *d_df_du_k, T *s_df_du, T *s_Y, const T *s_qd, const T *s_u, T *s_X, T *s_SP, T *s_qdd, const robotModel<T> *d_robotModel, const T gravity, const int lane"),
     "id": ("inverse_dynamics_inner_branch", "Compute the RNEA (Recursive Newton-Euler Algorithm)",
            "T *s_c, const T *s_qd, const T *s_qddin, T *s_X, T *s_SP, const robotModel<T> *d_robotModel, const T gravity, const int lane"),
     "idgrad": ("inverse_dynamics_gradient_inner_branch", "Computes the gradient of inverse dynamics",
@@ -451,8 +451,10 @@ _BRANCH_MODES = {
 
 def _emit_branch_inner(self, mode, use_thread_group=False):
     """One emitter for the five inners of the branch-frame path; `mode` selects the stages (see gen_branch_frame_components)."""
-    # "fdgrad_stream" (the forward-dynamics-gradient KERNEL of LDS-capacity-bound robots, gen_fd_stream_out): the image holds ONE half of the result
-    # (n^2 values) at a time - d/dqd is solved and stored right after the factorisation, then the same LDS takes d/dq: more resident waves per CU
+    # "fdgrad_stream" (the forward-dynamics-gradient KERNEL of LDS-capacity-bound robots, tuning stream_out): the image holds ONE half of the result
+    # (n^2 values) at a time - pass 1 assembles dc/dqd there, every lane parks its own column (component rows only: n x NCmax values per solve),
+    # pass 2 overwrites the same entries with dc/dq; both columns are solved together at the end and leave one half after the other: the
+    # staging shrinks from 2 n^2 to n^2 + n NCmax values per solve = more resident waves per CU
     stream = mode == "fdgrad_stream"
     fname, fdoc, fsig = _BRANCH_MODES[mode]
     if stream:
@@ -471,7 +473,7 @@ def _emit_branch_inner(self, mode, use_thread_group=False):
     H = 24
     A = self.gen_add_code_line
     outdoc = {"fdgrad": "s_df_du receives -Minv*dc/du in the device layout [col*n + row] (2*NUM_JOINTS*NUM_JOINTS values; also the assembly area of dc/du)" if not stream else
-              "d_df_du_k is this solve's record in global memory (2*NUM_JOINTS*NUM_JOINTS values, layout [col*n + row]; nullptr: nothing is stored); s_df_du is LDS for ONE half of it (NUM_JOINTS*NUM_JOINTS values)",
+              "d_df_du_k is this solve's record in global memory (2*NUM_JOINTS*NUM_JOINTS values, layout [col*n + row]; nullptr: nothing is stored); s_df_du is LDS for ONE half of it (NUM_JOINTS*NUM_JOINTS values); s_Y is LDS for the parked dc/dqd columns (NUM_JOINTS*%d values)" % max(len(s_) for s_ in P["shapes"]),
               "id": "s_c receives the joint torques (lane of joint j writes s_c[j]); s_qddin may be nullptr (zero accelerations)",
               "idgrad": "s_dc_du receives dc/du in the device layout [col*n + row], col in [0,2n) = [d/dq | d/dqd]",
               "fd": "s_qdd receives the joint accelerations (it also holds tau - c on the way)",
@@ -978,9 +980,14 @@ def _emit_branch_inner(self, mode, use_thread_group=False):
         self.gen_add_end_function()
         return
 
-    def column_solves(cols):
-        """df/du = -M^-1 dc/du for the column(s) this lane owns: `cols` = [(register array, column offset in the image)]; the factors are read once per call."""
-        A("// df/du = -M^-1 dc/du for the column%s this lane owns (rows of its component; all other rows of the column are zero)" % ("s" if len(cols) > 1 else ""))
+    def column_solves(parked):
+        """df/du = -M^-1 dc/du for the two columns this lane owns (the factors are read once for both).  parked (the half-image form): d/dq comes from
+        the image, d/dqd from this lane's parked copy; -d/dq goes back to the image, -d/dqd stays in registers (yk) until the first half has left."""
+        A("// df/du = -M^-1 dc/du for the two columns this lane owns (rows of its component; all other rows of the column are zero)")
+        if parked:
+            A("T yk[%d]; // this lane's finished d/dqd column, kept until the d/dq half has left the image" % NCmax)
+            A("#pragma unroll")
+            A("for (int i = 0; i < %d; i++) { yk[i] = Z; }" % NCmax)
         for si, sig in enumerate(shapes):
             Nc = len(sig)
             an = ancs[si]
@@ -989,38 +996,43 @@ def _emit_branch_inner(self, mode, use_thread_group=False):
                 for i in an[k] + [k]:
                     midx[(i, k)] = len(midx)
             A("%sif (shape == %d) {" % ("" if si == 0 else "else ", si), True)
-            A("T " + ", ".join("%s[%d]" % (v, Nc) for v, _ in cols) + ";")
+            A("T x[%d], y[%d];" % (Nc, Nc))
             A("#pragma unroll")
-            A("for (int i = 0; i < %d; i++) { " % Nc + " ".join("%s[i] = s_df_du[(%d + jid)*%d + cbase + i];" % (v, o, n) for v, o in cols) + " }")
+            if parked:
+                A("for (int i = 0; i < %d; i++) { x[i] = s_df_du[jid*%d + cbase + i]; y[i] = s_Y[jid*%d + i]; }" % (Nc, n, NCmax))
+            else:
+                A("for (int i = 0; i < %d; i++) { x[i] = s_df_du[jid*%d + cbase + i]; y[i] = s_df_du[(%d + jid)*%d + cbase + i]; }" % (Nc, n, n, n))
             for k in range(Nc - 1, 0, -1):
                 for i in an[k]:
-                    A("{ const T uu = s_Uc[%d]; " % midx[(i, k)] + " ".join("%s[%d] -= uu*%s[%d];" % (v, i, v, k) for v, _ in cols) + " }")
+                    A("{ const T uu = s_Uc[%d]; x[%d] -= uu*x[%d]; y[%d] -= uu*y[%d]; }" % (midx[(i, k)], i, k, i, k))
             for k in range(Nc):
-                A("{ const T rr = s_Uc[%d]; " % midx[(k, k)] + " ".join("%s[%d] *= rr;" % (v, k) for v, _ in cols) + " }")
+                A("{ const T rr = s_Uc[%d]; x[%d] *= rr; y[%d] *= rr; }" % (midx[(k, k)], k, k))
             for k in range(1, Nc):
                 for i in an[k]:
-                    A("{ const T uu = s_Uc[%d]; " % midx[(i, k)] + " ".join("%s[%d] -= uu*%s[%d];" % (v, k, v, i) for v, _ in cols) + " }")
+                    A("{ const T uu = s_Uc[%d]; x[%d] -= uu*x[%d]; y[%d] -= uu*y[%d]; }" % (midx[(i, k)], k, i, k, i))
             A("#pragma unroll")
-            A("for (int i = 0; i < %d; i++) { " % Nc + " ".join("s_df_du[(%d + jid)*%d + cbase + i] = -%s[i];" % (o, n, v) for v, o in cols) + " }")
+            if parked:
+                A("for (int i = 0; i < %d; i++) { s_df_du[jid*%d + cbase + i] = -x[i]; yk[i] = -y[i]; }" % (Nc, n))
+            else:
+                A("for (int i = 0; i < %d; i++) { s_df_du[jid*%d + cbase + i] = -x[i]; s_df_du[(%d + jid)*%d + cbase + i] = -y[i]; }" % (Nc, n, n, n))
             self.gen_add_end_control_flow()
 
-    def store_half(dst_off, clear):
-        """stream form: the image (one half of the record, n^2 values) leaves with 16-byte stores of this lane group; then it is cleared for the other half."""
+    def store_half(dst_off):
+        """half-image form: the image (one half of the record, n^2 values) leaves with 16-byte stores of this lane group."""
         self.gen_add_sync(use_thread_group)
         A("if (d_df_du_k != nullptr) {", True)
         A("for (int e = 4*lane; e + 3 < %d; e += %d) { T tmp[4]; __builtin_memcpy(tmp, __builtin_assume_aligned(s_df_du + e, 4*sizeof(T) < 16 ? 4*sizeof(T) : 16), 4*sizeof(T)); grid_store4(d_df_du_k + %d + e, tmp); }" % (n * n, 4 * lanes, dst_off))
         self.gen_add_end_control_flow()
-        if clear:
-            A("for (int e = lane; e < %d; e += %d) {" % (n * n // 4, lanes), True)
-            A("#pragma unroll")
-            A("for (int r = 0; r < 4; r++) { s_df_du[4*e + r] = Z; }")
-            self.gen_add_end_control_flow()
-            self.gen_add_sync(use_thread_group)
 
     if stream:
-        A("// d/dqd half: solved and stored now, its LDS then takes the d/dq half")
-        column_solves([("y", 0)])
-        store_half(n * n, True)
+        A("// half-image form: pass 1 assembled dc/dqd in the image; every lane parks its own column (rows of its component), pass 2 then overwrites")
+        A("// exactly the same entries with dc/dq (same index pattern), so the image needs no clearing in between")
+        for si, sig in enumerate(shapes):
+            A("%sif (shape == %d) {" % ("" if si == 0 else "else ", si), True)
+            A("#pragma unroll")
+            A("for (int i = 0; i < %d; i++) { s_Y[jid*%d + i] = s_df_du[jid*%d + cbase + i]; }" % (len(sig), NCmax, n))
+            self.gen_add_end_control_flow()
+        self.gen_add_sync(use_thread_group)
     # ------------------------------------------------------------------ pass 2
     TS(6)
     A("// the acceleration-dependent parts: a += sum over the ancestors of S_i qdd_i, f^C += sum over the subtree of I_k da_k")
@@ -1077,11 +1089,17 @@ def _emit_branch_inner(self, mode, use_thread_group=False):
     self.gen_add_sync(use_thread_group)
     # ------------------------------------------------------------------ column solves
     TS(7)
+    column_solves(stream)
     if stream:
-        column_solves([("x", 0)])
-        store_half(0, False)
-    else:
-        column_solves([("x", 0), ("y", n)])
+        store_half(0)
+        self.gen_add_sync(use_thread_group)  # (the reads of that store are ahead of the writes below in the wave's LDS queue anyway: a compiler fence on the GPU)
+        A("// now the d/dqd half: same sparsity, every entry inside the component blocks is overwritten, everything else is still zero")
+        for si, sig in enumerate(shapes):
+            A("%sif (shape == %d) {" % ("" if si == 0 else "else ", si), True)
+            A("#pragma unroll")
+            A("for (int i = 0; i < %d; i++) { s_df_du[jid*%d + cbase + i] = yk[i]; }" % (len(sig), n))
+            self.gen_add_end_control_flow()
+        store_half(n * n)
     if ts_mode:
         self.gen_add_sync(use_thread_group)
         TS(8)

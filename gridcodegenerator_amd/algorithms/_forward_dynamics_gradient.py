@@ -115,7 +115,7 @@ def gen_forward_dynamics_gradient_stream_device(self, use_thread_group=False):
     """Device function behind the forward_dynamics_gradient kernel where gen_lds_layout chose the streamed output (self.fd_stream_out)."""
     n = self.model.n
     self.gen_add_func_doc("Computes the gradient of forward dynamics and stores it to global memory half by half (lane-group cooperative; the kernel's form where LDS capacity bounds the resident waves)",
-                          ["d/dqd (columns n..2n-1) leaves right after the factorisation, d/dq (columns 0..n-1) at the end; all lanes of the solve's lane group must call it"],
+                          ["one half of the record is staged at a time (the dc/dqd columns wait in s_work[FD_DU_OFF_YPARK..] while dc/dq is assembled); all lanes of the solve's lane group must call it"],
                           ["d_df_du_k is this solve's record in global memory, 2*NUM_JOINTS*NUM_JOINTS values [col*n + row] (nullptr: lane group without a solve, nothing is stored)",
                            "s_half is LDS for one half of the record: NUM_JOINTS*NUM_JOINTS = " + str(n * n) + " values",
                            "s_q is the vector of joint positions", "s_qd is the vector of joint velocities", "s_u is the vector of input torques",
@@ -127,7 +127,7 @@ def gen_forward_dynamics_gradient_stream_device(self, use_thread_group=False):
     self.gen_add_code_line("void forward_dynamics_gradient_stream_device(T *d_df_du_k, T *s_half, const T *s_q, const T *s_qd, const T *s_u, T *s_work, const robotModel<T> *d_robotModel, const T gravity, const int lane) {", True)
     self.gen_add_code_line("T *s_X = &s_work[GRID_OFF_X]; T *s_SP = &s_work[FD_DU_OFF_SP]; T *s_qdd = &s_work[FD_DU_OFF_QDD];")
     self.gen_load_update_XImats_helpers_function_call(use_thread_group)
-    self.gen_add_code_line("forward_dynamics_gradient_inner_branch_stream<T>(d_df_du_k, s_half, s_qd, s_u, s_X, s_SP, s_qdd, d_robotModel, gravity, lane);")
+    self.gen_add_code_line("forward_dynamics_gradient_inner_branch_stream<T>(d_df_du_k, s_half, &s_work[FD_DU_OFF_YPARK], s_qd, s_u, s_X, s_SP, s_qdd, d_robotModel, gravity, lane);")
     self.gen_add_sync(use_thread_group)
     self.gen_add_end_function()
 

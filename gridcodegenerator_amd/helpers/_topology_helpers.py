@@ -71,13 +71,22 @@ def gen_lds_layout(self):
     # forward_dynamics_gradient kernel of LDS-capacity-bound branch-frame robots: stage one half of the record at a time if that makes more waves
     # resident on a CU (160 KB, allocation granule 512 B, at most 8 waves at 256 VGPRs)
     off["FD_OUT_PER_SOLVE"] = off["OUT_PER_SOLVE"]
+    off["FD_YPARK"] = 0
     want = self.tuning["stream_out"]
     self.fd_stream_out = False
     if getattr(self, "branch_frame", False) and want is not False and (n * n) % 4 == 0 and int(self.tuning["debug_stop"]) == 0 and not self.tuning["out_half"]:
         spw = 64 // self.lanes_per_solve
-        waves = lambda out: min(8, (160 * 1024) // (-(-(spw * (off["FD_TOTAL"] + out) * 4) // 512) * 512))
-        if want is True or (off["FD_TOTAL"] < off["TOTAL"] and waves(n * n) > waves(off["OUT_PER_SOLVE"])):
+        park = _pad4(n * max(len(s_) for s_ in self.branch_plan["shapes"]))  # every lane's dc/dqd column, rows of its component
+        tot2 = off["FD_TOTAL"] + park
+        if (tot2 % 64 == 0) if spw <= 2 else ((tot2 // 4) % 2 == 0):
+            tot2 += 4
+        waves = lambda slice_, out: min(8, (160 * 1024) // (-(-(spw * (slice_ + out) * 4) // 512) * 512))
+        if want is True or (off["FD_TOTAL"] < off["TOTAL"] and waves(tot2, n * n) > waves(off["FD_TOTAL"], off["OUT_PER_SOLVE"])):
             self.fd_stream_out = True
+            off["FD_YPARK"] = off["FD_TOTAL"]
+            off["FD_TOTAL"] = tot2
+            if tot2 > off["TOTAL"]:
+                off["TOTAL"] = tot2 + (4 if ((tot2 // 4) % 2 == 0) else 0)
             off["FD_OUT_PER_SOLVE"] = n * n
     return off
 
