@@ -25,6 +25,8 @@ TUNING_DEFAULTS = {
     "min_waves": 0,             # second __launch_bounds__ argument (minimum waves per SIMD); 0 = compiler's choice
     "so_unroll": None,          # inner-loop unrolling of idsva_so (None = full; subtree mapping only)
     "so_mapping": "balanced",   # balanced | subtree: work distribution of the idsva_so main loops (algorithms/_idsva_so.py: gen_idsva_so_items)
+    "so_direct": "auto",        # auto | True: second-order kernels write their 4 n^3 record straight to global memory instead of staging it in LDS
+                                # (auto = only where the record does not fit LDS, algorithms/_idsva_so.py: gen_idsva_so_direct)
     "dpp_asm": True,            # lane-group scans as single v_fmac_f32_dpp instructions (inline asm) instead of builtin DPP move + FMA
     "tip_chain": "select",      # select | lds: how the tip-frame chain hands (R, p) to the owning lane
     "nt_store": True,           # non-temporal output stores

@@ -46,7 +46,9 @@ def gen_idsva_so_direct(self):
     the solve's record in global memory (store-issue bound, see the module docstring - but the only way for large robots), and fdsva_so reads the
     idsva_so tensors back from a global workspace (gridData::d_idsva_so) instead of LDS."""
     n = self.model.n
-    return self.gen_idsva_so_mode() is not None and (28 * n + 4 * n + 16 + 4 * n * n * n) * 4 > 150 * 1024
+    if self.gen_idsva_so_mode() is None:
+        return False
+    return self.tuning["so_direct"] is True or (28 * n + 4 * n + 16 + 4 * n * n * n) * 4 > 150 * 1024
 
 
 def gen_idsva_so_available(self):

@@ -19,6 +19,8 @@ for cfg in "atlas 16384" "hyq 4096"; do
   rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS --kernel-trace --output-format csv -d $O/${R}_pmc_sq -o run -- python3 tools/bench_variant.py $R $N - > /dev/null 2> $O/${R}_pmc_sq.err || exit 1
 done
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/so_trace -o run -- python3 tools/bench_idsva_so.py iiwa14 65536 > $O/so_bench.jsonl 2> $O/so_trace.err || exit 1
+python3 tools/bench_idsva_so.py hyq 4096 >> $O/so_bench.jsonl 2> /dev/null || exit 1
+python3 tools/bench_idsva_so.py atlas 1024 >> $O/so_bench.jsonl 2> /dev/null || exit 1
 python3 tests/tools/bench_components.py > $O/components.jsonl 2> /dev/null || exit 1
 python3 tools/bench_robots.py > $O/robots.jsonl 2> /dev/null || exit 1
 echo done
