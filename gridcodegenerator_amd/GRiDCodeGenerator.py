@@ -270,6 +270,13 @@ class GRiDCodeGenerator:
                                  "const int FD_DU_OFF_SP = " + str(lds["FD_SP"]) + "; const int FD_DU_OFF_QDD = " + str(lds["FD_QDD"]) + "; const int FD_DU_OFF_YPARK = " + str(lds["FD_YPARK"]) + ";",
                                  "const int FD_DU_SUGGESTED_THREADS = " + str(fd_threads) + ";",
                                  "const int FD_DU_OUT_PER_SOLVE = " + str(lds["FD_OUT_PER_SOLVE"]) + "; // staging of that kernel" + (": ONE half of the record at a time (d/dqd leaves after the factorisation, then d/dq: more resident waves per CU)" if self.fd_stream_out else "") + "; the _single_timing twin stages GRID_OUT_PER_SOLVE"])
+        self.gen_add_code_line("// per-kernel slices of the stand-alone kernels (ID = inverse_dynamics, ID_DU = its gradient, MINV = direct_minv, FD = forward_dynamics, ABA = aba): elements per")
+        self.gen_add_code_line("// solve, staging elements per solve, offsets of the path-axis scratch and of M^-1 inside the slice, best block size.  Robots on the branch-frame path")
+        self.gen_add_code_line("// carve compact slices (IN | X | path axes [| M^-1]); everyone else uses the general slice")
+        for k in ("ID", "ID_DU", "MINV", "FD", "ABA"):
+            K = lds["KERNELS"][k]
+            self.gen_add_code_line("const int %s_LDS_PER_SOLVE = %d; const int %s_OUT_PER_SOLVE = %d; const int %s_OFF_SP = %d; const int %s_OFF_MINV = %d; const int %s_SUGGESTED_THREADS = %s;"
+                                   % (k, K["LDS"], k, K["OUT"], k, K["SP"], k, K["MINV"], k, "64" if K["compact"] else "SUGGESTED_THREADS"))
         for k in ("ID", "MINV", "FD", "ABA", "ID_DU", "FD_DU"):
             self.gen_add_code_line("const int " + k + "_DYNAMIC_SHARED_MEM_COUNT = " + str(count) + ";")
         self.gen_add_code_lines(["const int ID_DU_MAX_SHARED_MEM_COUNT = " + str(count) + ";",

@@ -190,7 +190,7 @@ def gen_aba_kernel(self, use_thread_group=False, single_call_timing=False):
     self.gen_add_code_line("template <typename T>")
     self.gen_add_code_line("__global__ GRID_LAUNCH_BOUNDS")
     self.gen_add_code_line(func_def, True)
-    self.gen_kernel_prologue("GRID_LDS_PER_SOLVE")
+    self.gen_kernel_prologue("ABA_LDS_PER_SOLVE")
     self.gen_add_code_lines(["T *s_q_qd_tau = &s_mem[GRID_OFF_IN]; T *s_q = s_q_qd_tau; T *s_qd = &s_q_qd_tau[%d]; T *s_tau = &s_q_qd_tau[%d];" % (n, 2 * n),
                              "T *s_qdd = &s_out_all[grp*%d];" % n])
     if single_call_timing:
@@ -238,7 +238,7 @@ def gen_aba_host(self, mode=0):
     self.gen_add_code_line("// then call the kernel")
     if single_call_timing:
         self.gen_add_code_line("struct timespec start, end; clock_gettime(CLOCK_MONOTONIC,&start);")
-    self.gen_add_code_lines(["hipLaunchKernelGGL((" + kern + "),block_dimms,thread_dimms,grid_lds_bytes<T>(thread_dimms),0,hd_data->d_qdd,hd_data->d_q_qd_u,stride_q_qd,d_robotModel,gravity,num_timesteps);",
+    self.gen_add_code_lines(["hipLaunchKernelGGL((" + kern + "),block_dimms,thread_dimms,grid_lds_bytes<T>(thread_dimms, ABA_LDS_PER_SOLVE, ABA_OUT_PER_SOLVE),0,hd_data->d_qdd,hd_data->d_q_qd_u,stride_q_qd,d_robotModel,gravity,num_timesteps);",
                              "gpuErrchk(hipGetLastError()); gpuErrchk(hipDeviceSynchronize());"])
     if single_call_timing:
         self.gen_add_code_line("clock_gettime(CLOCK_MONOTONIC,&end);")

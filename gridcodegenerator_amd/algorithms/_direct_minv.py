@@ -187,8 +187,8 @@ def gen_direct_minv_device(self, use_thread_group=False):
                            "lane is the caller's lane index inside the solve's lane group"], None)
     self.gen_add_code_line("template <typename T>")
     self.gen_add_code_line("__device__ __forceinline__")
-    self.gen_add_code_line("void direct_minv_device(T *s_Minv, const T *s_q, T *s_work, const robotModel<T> *d_robotModel, const int lane) {", True)
-    self.gen_add_code_line("T *s_X = &s_work[GRID_OFF_X]; T *s_U = &s_work[GRID_OFF_U]; T *s_T = &s_work[GRID_OFF_T];")
+    self.gen_add_code_line("void direct_minv_device(T *s_Minv, const T *s_q, T *s_work, const robotModel<T> *d_robotModel, const int lane, const int off_sp = GRID_OFF_SP) {", True)
+    self.gen_add_code_line("T *s_X = &s_work[GRID_OFF_X]; T *s_U = &s_work[GRID_OFF_U]; T *s_T = &s_work[GRID_OFF_T]; (void)off_sp; // (off_sp: path-axis scratch of branch-frame robots inside s_work; the stand-alone kernel carves a compact slice)")
     self.gen_load_update_XImats_helpers_function_call(use_thread_group)
     if self.tip_frame:  # serial revolute chains: M from the tip-frame composites, factored in registers, one unit-vector solve per lane
         self.gen_add_code_line("(void)s_T;")
@@ -198,7 +198,7 @@ def gen_direct_minv_device(self, use_thread_group=False):
         return
     if getattr(self, "branch_components", False):  # branched revolute robots: tree-sparse factorisation of M from the branch-frame composites, one unit-vector solve per lane
         self.gen_add_code_line("(void)s_T; (void)s_U;")
-        self.gen_add_code_line("direct_minv_inner_branch<T>(s_Minv, s_X, &s_work[GRID_OFF_SP], d_robotModel, lane);")
+        self.gen_add_code_line("direct_minv_inner_branch<T>(s_Minv, s_X, &s_work[off_sp], d_robotModel, lane);")
         self.gen_add_sync(use_thread_group)
         self.gen_add_end_function()
         return
@@ -219,9 +219,9 @@ def gen_direct_minv_kernel(self, use_thread_group=False, single_call_timing=Fals
     self.gen_add_code_line("template <typename T>")
     self.gen_add_code_line("__global__ GRID_LAUNCH_BOUNDS")
     self.gen_add_code_line(func_def, True)
-    self.gen_kernel_prologue("GRID_LDS_PER_SOLVE")
+    self.gen_kernel_prologue("MINV_LDS_PER_SOLVE")
     self.gen_add_code_lines(["T *s_q = &s_mem[GRID_OFF_IN];",
-                             "T *s_Minv = &s_mem[GRID_OFF_MINV]; T *s_out = &s_out_all[grp*%d];" % (n * n)])
+                             "T *s_Minv = &s_mem[MINV_OFF_MINV]; T *s_out = &s_out_all[grp*%d]; (void)s_out;" % (n * n)])
     if single_call_timing:
         self.gen_add_code_line("const int k = 0; const int kc = 0; const bool valid = (blockIdx.x + blockIdx.y == 0) && (grp == 0); const int lane = lane_id; const int NUM_TIMESTEPS_OUT = 1;")
         self.gen_add_code_line("if (!valid) {return;}")
@@ -231,18 +231,32 @@ def gen_direct_minv_kernel(self, use_thread_group=False, single_call_timing=Fals
     if single_call_timing:
         self.gen_add_code_line("for (int rep = 0; rep < NUM_TIMESTEPS; rep++){", True)
     self.gen_add_code_line("// compute")
-    self.gen_add_code_line("direct_minv_device<T>(s_Minv, s_q, s_mem, d_robotModel, lane);")
+    self.gen_add_code_line("direct_minv_device<T>(s_Minv, s_q, s_mem, d_robotModel, lane, MINV_OFF_SP);")
     if single_call_timing:
         self.gen_add_end_control_flow()
-    self.gen_add_code_line("// upper triangle only in the output record")
-    self.gen_add_parallel_loop("ind", str(n * n), use_thread_group)
-    self.gen_add_code_line("const int row = ind %% %d; const int col = ind / %d;" % (n, n))
-    self.gen_add_code_line("s_out[ind] = (row <= col) ? s_Minv[col*%d + row] : static_cast<T>(0);" % self.minv_ld)
-    self.gen_add_end_control_flow()
-    if single_call_timing:
-        self.gen_kernel_save_result_single_timing("Minv", n * n, use_thread_group, "s_out")
+    direct_out = self.gen_lds_layout()["KERNELS"]["MINV"]["OUT"] == 0 and not single_call_timing
+    if direct_out:
+        self.gen_add_code_line("// upper triangle only in the output record; compact slice: no second staging copy, every lane gathers 16-byte pieces of the record from s_Minv")
+        self.gen_add_code_line("if (valid) {", True)
+        self.gen_add_code_line("T *dst = &d_Minv[static_cast<size_t>(kc)*%d];" % (n * n))
+        self.gen_add_code_line("for (int e = 4*lane; e + 3 < %d; e += 4*GRID_LANES_PER_SOLVE) {" % (n * n), True)
+        self.gen_add_code_line("T tmp[4];")
+        self.gen_add_code_line("#pragma unroll")
+        self.gen_add_code_line("for (int r = 0; r < 4; r++) { const int ind = e + r; const int row = ind %% %d; const int col = ind / %d; tmp[r] = (row <= col) ? s_Minv[col*%d + row] : static_cast<T>(0); }" % (n, n, self.minv_ld))
+        self.gen_add_code_line("grid_store4(dst + e, tmp);")
+        self.gen_add_end_control_flow()
+        self.gen_add_end_control_flow()
+        self.gen_add_sync(use_thread_group)
     else:
-        self.gen_kernel_save_result("Minv", n * n, n * n, use_thread_group, "s_out")
+        self.gen_add_code_line("// upper triangle only in the output record")
+        self.gen_add_parallel_loop("ind", str(n * n), use_thread_group)
+        self.gen_add_code_line("const int row = ind %% %d; const int col = ind / %d;" % (n, n))
+        self.gen_add_code_line("s_out[ind] = (row <= col) ? s_Minv[col*%d + row] : static_cast<T>(0);" % self.minv_ld)
+        self.gen_add_end_control_flow()
+        if single_call_timing:
+            self.gen_kernel_save_result_single_timing("Minv", n * n, use_thread_group, "s_out")
+        else:
+            self.gen_kernel_save_result("Minv", n * n, n * n, use_thread_group, "s_out")
     if not single_call_timing:
         self.gen_add_end_control_flow()
     self.gen_add_end_function()
@@ -273,7 +287,7 @@ def gen_direct_minv_host(self, mode=0):
     self.gen_add_code_line("const T *d_in = USE_COMPRESSED_MEM ? hd_data->d_q : hd_data->d_q_qd_u;")
     if single_call_timing:
         self.gen_add_code_line("struct timespec start, end; clock_gettime(CLOCK_MONOTONIC,&start);")
-    self.gen_add_code_lines(["hipLaunchKernelGGL((" + kern + "),block_dimms,thread_dimms,grid_lds_bytes<T>(thread_dimms),0,hd_data->d_Minv,d_in,stride_q,d_robotModel,num_timesteps);",
+    self.gen_add_code_lines(["hipLaunchKernelGGL((" + kern + "),block_dimms,thread_dimms,grid_lds_bytes<T>(thread_dimms, MINV_LDS_PER_SOLVE, " + ("GRID_OUT_PER_SOLVE" if single_call_timing else "MINV_OUT_PER_SOLVE") + "),0,hd_data->d_Minv,d_in,stride_q,d_robotModel,num_timesteps);",
                              "gpuErrchk(hipGetLastError()); gpuErrchk(hipDeviceSynchronize());"])
     if single_call_timing:
         self.gen_add_code_line("clock_gettime(CLOCK_MONOTONIC,&end);")

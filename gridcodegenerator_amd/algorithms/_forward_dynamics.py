@@ -116,7 +116,7 @@ def gen_forward_dynamics_device(self, use_thread_group=False):
                            "lane is the caller's lane index inside the solve's lane group"], None)
     self.gen_add_code_line("template <typename T>")
     self.gen_add_code_line("__device__ __forceinline__")
-    self.gen_add_code_line("void forward_dynamics_device(T *s_qdd, const T *s_q, const T *s_qd, const T *s_u, T *s_work, const robotModel<T> *d_robotModel, const T gravity, const int lane) {", True)
+    self.gen_add_code_line("void forward_dynamics_device(T *s_qdd, const T *s_q, const T *s_qd, const T *s_u, T *s_work, const robotModel<T> *d_robotModel, const T gravity, const int lane, const int off_sp = GRID_OFF_SP) {", True)
     self.gen_add_code_line("T *s_X = &s_work[GRID_OFF_X]; T *s_U = &s_work[GRID_OFF_U]; T *s_T = &s_work[GRID_OFF_T]; T *s_Minv = &s_work[GRID_OFF_MINV];")
     self.gen_load_update_XImats_helpers_function_call(use_thread_group)
     if self.tip_frame:  # serial revolute chains: M from the tip-frame composites, factored in registers
@@ -127,7 +127,7 @@ def gen_forward_dynamics_device(self, use_thread_group=False):
         return
     if getattr(self, "branch_components", False):  # branched revolute robots: M from the branch-frame composites, tree-sparse factorisation
         self.gen_add_code_line("(void)s_T; (void)s_U; (void)s_Minv;")
-        self.gen_add_code_line("forward_dynamics_inner_branch<T>(s_qdd, s_qd, s_u, s_X, &s_work[GRID_OFF_SP], d_robotModel, gravity, lane);")
+        self.gen_add_code_line("forward_dynamics_inner_branch<T>(s_qdd, s_qd, s_u, s_X, &s_work[off_sp], d_robotModel, gravity, lane);")
         self.gen_add_sync(use_thread_group)
         self.gen_add_end_function()
         return
@@ -149,7 +149,7 @@ def gen_forward_dynamics_kernel(self, use_thread_group=False, single_call_timing
     self.gen_add_code_line("template <typename T>")
     self.gen_add_code_line("__global__ GRID_LAUNCH_BOUNDS")
     self.gen_add_code_line(func_def, True)
-    self.gen_kernel_prologue("GRID_LDS_PER_SOLVE")
+    self.gen_kernel_prologue("FD_LDS_PER_SOLVE")
     self.gen_add_code_lines(["T *s_q_qd_u = &s_mem[GRID_OFF_IN]; T *s_q = s_q_qd_u; T *s_qd = &s_q_qd_u[%d]; T *s_u = &s_q_qd_u[%d];" % (n, 2 * n),
                              "T *s_qdd = &s_out_all[grp*%d];" % n])
     if single_call_timing:
@@ -161,7 +161,7 @@ def gen_forward_dynamics_kernel(self, use_thread_group=False, single_call_timing
     if single_call_timing:
         self.gen_add_code_line("for (int rep = 0; rep < NUM_TIMESTEPS; rep++){", True)
     self.gen_add_code_line("// compute")
-    self.gen_add_code_line("forward_dynamics_device<T>(s_qdd, s_q, s_qd, s_u, s_mem, d_robotModel, gravity, lane);")
+    self.gen_add_code_line("forward_dynamics_device<T>(s_qdd, s_q, s_qd, s_u, s_mem, d_robotModel, gravity, lane, FD_OFF_SP);")
     if single_call_timing:
         self.gen_add_end_control_flow()
     if single_call_timing:
@@ -197,7 +197,7 @@ def gen_forward_dynamics_host(self, mode=0):
     self.gen_add_code_line("// then call the kernel")
     if single_call_timing:
         self.gen_add_code_line("struct timespec start, end; clock_gettime(CLOCK_MONOTONIC,&start);")
-    self.gen_add_code_lines(["hipLaunchKernelGGL((" + kern + "),block_dimms,thread_dimms,grid_lds_bytes<T>(thread_dimms),0,hd_data->d_qdd,hd_data->d_q_qd_u,stride_q_qd_u,d_robotModel,gravity,num_timesteps);",
+    self.gen_add_code_lines(["hipLaunchKernelGGL((" + kern + "),block_dimms,thread_dimms,grid_lds_bytes<T>(thread_dimms, FD_LDS_PER_SOLVE, FD_OUT_PER_SOLVE),0,hd_data->d_qdd,hd_data->d_q_qd_u,stride_q_qd_u,d_robotModel,gravity,num_timesteps);",
                              "gpuErrchk(hipGetLastError()); gpuErrchk(hipDeviceSynchronize());"])
     if single_call_timing:
         self.gen_add_code_line("clock_gettime(CLOCK_MONOTONIC,&end);")

@@ -102,8 +102,8 @@ def gen_inverse_dynamics_device(self, use_thread_group=False, use_qdd_input=Fals
     self.gen_add_code_line("template <typename T>")
     self.gen_add_code_line("__device__ __forceinline__")
     self.gen_add_code_line("void inverse_dynamics_device(T *s_c, const T *s_q, const T *s_qd, " + ("const T *s_qdd, " if use_qdd_input else "") +
-                           "T *s_work, const robotModel<T> *d_robotModel, const T gravity, const int lane) {", True)
-    self.gen_add_code_line("T *s_X = &s_work[GRID_OFF_X];")
+                           "T *s_work, const robotModel<T> *d_robotModel, const T gravity, const int lane, const int off_sp = GRID_OFF_SP) {", True)
+    self.gen_add_code_line("T *s_X = &s_work[GRID_OFF_X]; (void)off_sp; // (off_sp: where the path-axis scratch of branch-frame robots starts inside s_work; the stand-alone kernel carves a compact slice)")
     self.gen_load_update_XImats_helpers_function_call(use_thread_group)
     if self.tip_frame:  # serial revolute chains: RNEA in the tip link's frame, lane j produces c[j]
         self.gen_add_code_line("inverse_dynamics_inner_tip<T>(s_c, s_qd, %s, s_X, gravity, d_robotModel, lane);" % ("s_qdd" if use_qdd_input else "static_cast<const T *>(nullptr)"))
@@ -111,7 +111,7 @@ def gen_inverse_dynamics_device(self, use_thread_group=False, use_qdd_input=Fals
         self.gen_add_end_function()
         return
     if getattr(self, "branch_components", False):  # branched revolute robots: RNEA with every branch in its tip link's frame, the lane of joint j produces c[j]
-        self.gen_add_code_line("inverse_dynamics_inner_branch<T>(s_c, s_qd, %s, s_X, &s_work[GRID_OFF_SP], d_robotModel, gravity, lane);" % ("s_qdd" if use_qdd_input else "static_cast<const T *>(nullptr)"))
+        self.gen_add_code_line("inverse_dynamics_inner_branch<T>(s_c, s_qd, %s, s_X, &s_work[off_sp], d_robotModel, gravity, lane);" % ("s_qdd" if use_qdd_input else "static_cast<const T *>(nullptr)"))
         self.gen_add_sync(use_thread_group)
         self.gen_add_end_function()
         return
@@ -143,7 +143,7 @@ def gen_inverse_dynamics_kernel(self, use_thread_group=False, use_qdd_input=Fals
     self.gen_add_code_line("template <typename T>")
     self.gen_add_code_line("__global__ GRID_LAUNCH_BOUNDS")
     self.gen_add_code_line(func_def, True)
-    self.gen_kernel_prologue("GRID_LDS_PER_SOLVE")
+    self.gen_kernel_prologue("ID_LDS_PER_SOLVE")
     self.gen_add_code_lines(["T *s_q_qd = &s_mem[GRID_OFF_IN]; T *s_q = s_q_qd; T *s_qd = &s_q_qd[%d]; T *s_qdd = &s_q_qd[%d];" % (n, 2 * n),
                              "T *s_c = &s_out_all[grp*%d];" % n])
     if single_call_timing:
@@ -158,7 +158,7 @@ def gen_inverse_dynamics_kernel(self, use_thread_group=False, use_qdd_input=Fals
     if single_call_timing:
         self.gen_add_code_line("for (int rep = 0; rep < NUM_TIMESTEPS; rep++){", True)
     self.gen_add_code_line("// compute")
-    self.gen_add_code_line("inverse_dynamics_device<T>(s_c, s_q, s_qd, " + ("s_qdd, " if use_qdd_input else "") + "s_mem, d_robotModel, gravity, lane);")
+    self.gen_add_code_line("inverse_dynamics_device<T>(s_c, s_q, s_qd, " + ("s_qdd, " if use_qdd_input else "") + "s_mem, d_robotModel, gravity, lane, ID_OFF_SP);")
     if single_call_timing:
         self.gen_add_end_control_flow()
     if single_call_timing:
@@ -197,8 +197,8 @@ def gen_inverse_dynamics_host(self, mode=0):
     self.gen_add_code_line("const T *d_in = USE_COMPRESSED_MEM ? hd_data->d_q_qd : hd_data->d_q_qd_u;")
     if single_call_timing:
         self.gen_add_code_line("struct timespec start, end; clock_gettime(CLOCK_MONOTONIC,&start);")
-    self.gen_add_code_lines(["if (USE_QDD_FLAG) {hipLaunchKernelGGL((" + kern + "),block_dimms,thread_dimms,grid_lds_bytes<T>(thread_dimms),0,hd_data->d_c,d_in,stride_q_qd,hd_data->d_qdd,d_robotModel,gravity,num_timesteps);}",
-                             "else {hipLaunchKernelGGL((" + kern + "),block_dimms,thread_dimms,grid_lds_bytes<T>(thread_dimms),0,hd_data->d_c,d_in,stride_q_qd,d_robotModel,gravity,num_timesteps);}",
+    self.gen_add_code_lines(["if (USE_QDD_FLAG) {hipLaunchKernelGGL((" + kern + "),block_dimms,thread_dimms,grid_lds_bytes<T>(thread_dimms, ID_LDS_PER_SOLVE, ID_OUT_PER_SOLVE),0,hd_data->d_c,d_in,stride_q_qd,hd_data->d_qdd,d_robotModel,gravity,num_timesteps);}",
+                             "else {hipLaunchKernelGGL((" + kern + "),block_dimms,thread_dimms,grid_lds_bytes<T>(thread_dimms, ID_LDS_PER_SOLVE, ID_OUT_PER_SOLVE),0,hd_data->d_c,d_in,stride_q_qd,d_robotModel,gravity,num_timesteps);}",
                              "gpuErrchk(hipGetLastError()); gpuErrchk(hipDeviceSynchronize());"])
     if single_call_timing:
         self.gen_add_code_line("clock_gettime(CLOCK_MONOTONIC,&end);")

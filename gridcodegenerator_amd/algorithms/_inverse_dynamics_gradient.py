@@ -343,10 +343,10 @@ def gen_inverse_dynamics_gradient_device(self, use_thread_group=False, use_qdd_i
     self.gen_add_code_line("template <typename T>")
     self.gen_add_code_line("__device__ __forceinline__")
     self.gen_add_code_line("void inverse_dynamics_gradient_device(T *s_dc_du, const T *s_q, const T *s_qd, " + ("const T *s_qdd, " if use_qdd_input else "") +
-                           "T *s_work, const robotModel<T> *d_robotModel, const T gravity, const int lane) {", True)
-    self.gen_add_code_line("T *s_X = &s_work[GRID_OFF_X]; T *s_F = &s_work[GRID_OFF_F]; T *s_J = &s_work[GRID_OFF_J];")
+                           "T *s_work, const robotModel<T> *d_robotModel, const T gravity, const int lane, const int off_sp = GRID_OFF_SP, const int off_qdd = GRID_OFF_QDD) {", True)
+    self.gen_add_code_line("T *s_X = &s_work[GRID_OFF_X]; T *s_F = &s_work[GRID_OFF_F]; T *s_J = &s_work[GRID_OFF_J]; (void)off_sp; (void)off_qdd; // (off_sp / off_qdd: path-axis scratch and zero-qdd vector inside s_work; the stand-alone kernel carves a compact slice)")
     if not use_qdd_input:
-        self.gen_add_code_line("T *s_qdd = &s_work[GRID_OFF_QDD];")
+        self.gen_add_code_line("T *s_qdd = &s_work[off_qdd];")
         self.gen_add_code_line("if (lane < %d) { s_qdd[lane] = static_cast<T>(0); }" % n)
     self.gen_load_update_XImats_helpers_function_call(use_thread_group)
     if self.tip_frame:  # serial revolute chains: assembled in the tip link's frame
@@ -357,7 +357,7 @@ def gen_inverse_dynamics_gradient_device(self, use_thread_group=False, use_qdd_i
         return
     if getattr(self, "branch_components", False):  # branched revolute robots: assembled with every branch in its tip link's frame
         self.gen_add_code_line("(void)s_F; (void)s_J;")
-        self.gen_add_code_line("inverse_dynamics_gradient_inner_branch<T>(s_dc_du, s_qd, s_qdd, s_X, &s_work[GRID_OFF_SP], d_robotModel, gravity, lane);")
+        self.gen_add_code_line("inverse_dynamics_gradient_inner_branch<T>(s_dc_du, s_qd, s_qdd, s_X, &s_work[off_sp], d_robotModel, gravity, lane);")
         self.gen_add_sync(use_thread_group)
         self.gen_add_end_function()
         return
@@ -386,7 +386,7 @@ def gen_inverse_dynamics_gradient_kernel(self, use_thread_group=False, use_qdd_i
     self.gen_add_code_line("template <typename T>")
     self.gen_add_code_line("__global__ GRID_LAUNCH_BOUNDS")
     self.gen_add_code_line(func_def, True)
-    self.gen_kernel_prologue("GRID_LDS_PER_SOLVE")
+    self.gen_kernel_prologue("ID_DU_LDS_PER_SOLVE")
     self.gen_add_code_lines(["T *s_q_qd = &s_mem[GRID_OFF_IN]; T *s_q = s_q_qd; T *s_qd = &s_q_qd[%d]; T *s_qdd = &s_q_qd[%d];" % (n, 2 * n),
                              "T *s_dc_du = &s_out_all[grp*%d];" % (2 * n * n)])
     if single_call_timing:
@@ -401,7 +401,7 @@ def gen_inverse_dynamics_gradient_kernel(self, use_thread_group=False, use_qdd_i
     if single_call_timing:
         self.gen_add_code_line("for (int rep = 0; rep < NUM_TIMESTEPS; rep++){", True)
     self.gen_add_code_line("// compute")
-    self.gen_add_code_line("inverse_dynamics_gradient_device<T>(s_dc_du, s_q, s_qd, " + ("s_qdd, " if use_qdd_input else "") + "s_mem, d_robotModel, gravity, lane);")
+    self.gen_add_code_line("inverse_dynamics_gradient_device<T>(s_dc_du, s_q, s_qd, " + ("s_qdd, " if use_qdd_input else "") + "s_mem, d_robotModel, gravity, lane, ID_DU_OFF_SP, GRID_OFF_IN + %d);" % (2 * n))
     if single_call_timing:
         self.gen_add_end_control_flow()
     if single_call_timing:
@@ -440,8 +440,8 @@ def gen_inverse_dynamics_gradient_host(self, mode=0):
     self.gen_add_code_line("const T *d_in = USE_COMPRESSED_MEM ? hd_data->d_q_qd : hd_data->d_q_qd_u;")
     if single_call_timing:
         self.gen_add_code_line("struct timespec start, end; clock_gettime(CLOCK_MONOTONIC,&start);")
-    self.gen_add_code_lines(["if (USE_QDD_FLAG) {hipLaunchKernelGGL((" + kern + "),block_dimms,thread_dimms,grid_lds_bytes<T>(thread_dimms),0,hd_data->d_dc_du,d_in,stride_q_qd,hd_data->d_qdd,d_robotModel,gravity,num_timesteps);}",
-                             "else {hipLaunchKernelGGL((" + kern + "),block_dimms,thread_dimms,grid_lds_bytes<T>(thread_dimms),0,hd_data->d_dc_du,d_in,stride_q_qd,d_robotModel,gravity,num_timesteps);}",
+    self.gen_add_code_lines(["if (USE_QDD_FLAG) {hipLaunchKernelGGL((" + kern + "),block_dimms,thread_dimms,grid_lds_bytes<T>(thread_dimms, ID_DU_LDS_PER_SOLVE, ID_DU_OUT_PER_SOLVE),0,hd_data->d_dc_du,d_in,stride_q_qd,hd_data->d_qdd,d_robotModel,gravity,num_timesteps);}",
+                             "else {hipLaunchKernelGGL((" + kern + "),block_dimms,thread_dimms,grid_lds_bytes<T>(thread_dimms, ID_DU_LDS_PER_SOLVE, ID_DU_OUT_PER_SOLVE),0,hd_data->d_dc_du,d_in,stride_q_qd,d_robotModel,gravity,num_timesteps);}",
                              "gpuErrchk(hipGetLastError()); gpuErrchk(hipDeviceSynchronize());"])
     if single_call_timing:
         self.gen_add_code_line("clock_gettime(CLOCK_MONOTONIC,&end);")

@@ -217,7 +217,7 @@ static int id_device(grid_handle *h, const T *d_q_qd, int stride, const T *d_qdd
     GRID_ON_DEVICE(h);
     if ((rc = ensure_typed<T>(h))) return rc;
     launch_cfg c;
-    if ((rc = general_launch<T>(h, N, &c))) return rc;
+    if ((rc = make_launch<T>(h, N, grid::ID_SUGGESTED_THREADS, grid::GRID_MAX_SOLVES_PER_BLOCK, grid::ID_LDS_PER_SOLVE, grid::ID_OUT_PER_SOLVE, &c))) return rc;
     if (d_qdd) {
         hipLaunchKernelGGL((grid::inverse_dynamics_kernel<T>), c.grid, c.block, c.lds, (hipStream_t)stream, d_c, d_q_qd, stride, d_qdd, typed<T>(h).d_robotModel, gravity, N);
     } else {
@@ -235,7 +235,7 @@ static int id_grad_device(grid_handle *h, const T *d_q_qd, int stride, const T *
     GRID_ON_DEVICE(h);
     if ((rc = ensure_typed<T>(h))) return rc;
     launch_cfg c;
-    if ((rc = general_launch<T>(h, N, &c))) return rc;
+    if ((rc = make_launch<T>(h, N, grid::ID_DU_SUGGESTED_THREADS, grid::GRID_MAX_SOLVES_PER_BLOCK, grid::ID_DU_LDS_PER_SOLVE, grid::ID_DU_OUT_PER_SOLVE, &c))) return rc;
     if (d_qdd) {
         hipLaunchKernelGGL((grid::inverse_dynamics_gradient_kernel<T>), c.grid, c.block, c.lds, (hipStream_t)stream, d_dc_du, d_q_qd, stride, d_qdd,
                            typed<T>(h).d_robotModel, gravity, N);
@@ -255,7 +255,7 @@ static int minv_device(grid_handle *h, const T *d_q, int stride, int N, T *d_Min
     GRID_ON_DEVICE(h);
     if ((rc = ensure_typed<T>(h))) return rc;
     launch_cfg c;
-    if ((rc = general_launch<T>(h, N, &c))) return rc;
+    if ((rc = make_launch<T>(h, N, grid::MINV_SUGGESTED_THREADS, grid::GRID_MAX_SOLVES_PER_BLOCK, grid::MINV_LDS_PER_SOLVE, grid::MINV_OUT_PER_SOLVE, &c))) return rc;
     hipLaunchKernelGGL((grid::direct_minv_kernel<T>), c.grid, c.block, c.lds, (hipStream_t)stream, d_Minv, d_q, stride, typed<T>(h).d_robotModel, N);
     GRID_TRY(hipGetLastError());
     return 0;
@@ -269,7 +269,7 @@ static int fd_device(grid_handle *h, const T *d_q_qd_u, int stride, int N, T gra
     GRID_ON_DEVICE(h);
     if ((rc = ensure_typed<T>(h))) return rc;
     launch_cfg c;
-    if ((rc = general_launch<T>(h, N, &c))) return rc;
+    if ((rc = aba ? make_launch<T>(h, N, grid::ABA_SUGGESTED_THREADS, grid::GRID_MAX_SOLVES_PER_BLOCK, grid::ABA_LDS_PER_SOLVE, grid::ABA_OUT_PER_SOLVE, &c) : make_launch<T>(h, N, grid::FD_SUGGESTED_THREADS, grid::GRID_MAX_SOLVES_PER_BLOCK, grid::FD_LDS_PER_SOLVE, grid::FD_OUT_PER_SOLVE, &c))) return rc;
     if (aba) {
         hipLaunchKernelGGL((grid::aba_kernel<T>), c.grid, c.block, c.lds, (hipStream_t)stream, d_qdd, d_q_qd_u, stride, typed<T>(h).d_robotModel, gravity, N);
     } else {

@@ -88,6 +88,29 @@ def gen_lds_layout(self):
             if tot2 > off["TOTAL"]:
                 off["TOTAL"] = tot2 + (4 if ((tot2 // 4) % 2 == 0) else 0)
             off["FD_OUT_PER_SOLVE"] = n * n
+    # stand-alone kernels (inverse dynamics, its gradient, M^-1, forward dynamics): robots on the branch-frame path need only IN | X | path axes
+    # (| M^-1) of the general slice, and their staging is the kernel's own record - fewer bytes per solve = more resident waves
+    # (30-DoF humanoid, 16 384 solves: M^-1 107 -> see DESIGN.md section 6b)
+    ld = (n + 3) // 4 * 4
+    generic = {"LDS": off["TOTAL"], "OUT": off["OUT_PER_SOLVE"], "SP": off["SP"], "MINV": off["MINV"], "compact": False}
+    off["KERNELS"] = {k: dict(generic) for k in ("ID", "ID_DU", "MINV", "FD")}
+    # aba touches only IN | X | U | T (a prefix of the general slice) and stages n values
+    spw_ = 64 // self.lanes_per_solve
+    aba = off["MINV"] + (4 if ((off["MINV"] % 64 == 0) if spw_ <= 2 else ((off["MINV"] // 4) % 2 == 0)) else 0)
+    off["KERNELS"]["ABA"] = {"LDS": aba, "OUT": _pad4(n), "SP": off["SP"], "MINV": off["MINV"], "compact": aba + _pad4(n) < (off["TOTAL"] + off["OUT_PER_SOLVE"]) // 2}
+    if getattr(self, "branch_components", False) and not self.tuning["out_half"]:
+        from ..algorithms._branch_frame_gradient import branch_spare_in_image
+        P = self.branch_plan
+        spw = 64 // self.lanes_per_solve
+        fix = lambda t: t + 4 if ((t % 64 == 0) if spw <= 2 else ((t // 4) % 2 == 0)) else t
+        sp0 = off["U"]
+        sp_len = lambda image: _pad4(P["sp_size"] - (6 * P["D"] if (image and branch_spare_in_image(self, image)) else 0))
+        off["KERNELS"]["ID"] = {"LDS": fix(sp0 + sp_len(0)), "OUT": _pad4(n), "SP": sp0, "MINV": off["MINV"], "compact": True}
+        off["KERNELS"]["FD"] = dict(off["KERNELS"]["ID"])
+        off["KERNELS"]["ID_DU"] = {"LDS": fix(sp0 + sp_len(2 * n * n)), "OUT": _pad4(2 * n * n), "SP": sp0, "MINV": off["MINV"], "compact": True}
+        mv = sp0 + sp_len(n * ld)
+        # (n^2 a multiple of 4: the kernel gathers its output record straight from s_Minv with 16-byte stores, no second staging copy)
+        off["KERNELS"]["MINV"] = {"LDS": fix(mv + n * ld), "OUT": 0 if (n * n) % 4 == 0 else _pad4(n * n), "SP": sp0, "MINV": mv, "compact": True}
     return off
 
 
