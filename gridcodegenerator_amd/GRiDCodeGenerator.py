@@ -25,6 +25,11 @@ TUNING_DEFAULTS = {
     "min_waves": 0,             # second __launch_bounds__ argument (minimum waves per SIMD); 0 = compiler's choice
     "so_unroll": None,          # inner-loop unrolling of idsva_so (None = full; subtree mapping only)
     "so_mapping": "balanced",   # balanced | subtree: work distribution of the idsva_so main loops (algorithms/_idsva_so.py: gen_idsva_so_items)
+    "min_lanes": 8,             # smallest lane group (8 | 16 | 32 | 64): wider groups than the joint count needs leave lanes idle in the first-order kernels but
+                                # give the item loops of the second-order kernels more lanes per solve (and fewer solves' staging per wave)
+    "so_lanes": "auto",         # auto | off | 16: lane-group width of the second-order KERNELS.  Robots with 8-lane groups (n <= 8) get a second instance of the
+                                # library for 16-lane groups in the nested namespace `wide` and idsva_so_host / fdsva_so (and the C ABI) launch its kernels:
+                                # half the staging per wave, twice the lanes in the item loops (7-DoF arm, 65 536 solves: idsva_so 289 -> 195 us)
     "so_direct": "auto",        # auto | True: second-order kernels write their 4 n^3 record straight to global memory instead of staging it in LDS
                                 # (auto = only where the record does not fit LDS, algorithms/_idsva_so.py: gen_idsva_so_direct)
     "dpp_asm": True,            # lane-group scans as single v_fmac_f32_dpp instructions (inline asm) instead of builtin DPP move + FMA
@@ -121,6 +126,8 @@ class GRiDCodeGenerator:
             raise NotImplementedError("USE_DYNAMIC_SHARED_MEM=False (static __shared__ arrays) is not supported by the lane-group kernels: "
                                       "their LDS slice count depends on the launch's block size; keep the default (dynamic LDS)")
         self.tuning = resolve_tuning(tuning, COLS_PER_LANE)
+        self._ctor = dict(DEBUG_MODE=DEBUG_MODE, NEED_PRINT_MAT=NEED_PRINT_MAT, COLS_PER_LANE=COLS_PER_LANE, tuning=dict(tuning or {}))
+        self.nested = False  # True on the instance that emits the nested `wide` library of another generator
         self.robot = robotObj
         self.model = DuckRobot(robotObj)  # numeric tables; raises for robots outside the supported joint models
         self.code_str = ""
@@ -140,7 +147,9 @@ class GRiDCodeGenerator:
             COLS_PER_LANE = 2
         self.cols_per_lane = COLS_PER_LANE
         need = n if COLS_PER_LANE == 2 else 2 * n
-        lanes = 8 if COLS_PER_LANE == 2 else 16
+        lanes = max(8 if COLS_PER_LANE == 2 else 16, int(self.tuning["min_lanes"]))
+        if lanes not in (8, 16, 32, 64):
+            raise ValueError("tuning['min_lanes'] must be 8, 16, 32 or 64")
         while lanes < need:
             lanes *= 2
         self.lanes_per_solve = lanes          # lane j of a group <-> joint j; 6 lanes also carry the articulated inertia columns
@@ -323,7 +332,7 @@ class GRiDCodeGenerator:
                                  "    if (gpb < 1) {gpb = 1;}",
                                  "    return static_cast<size_t>(gpb)*(lds_per_solve + out_per_solve)*sizeof(T);",
                                  "}"])
-        self.gen_add_code_line("// Define custom structs")
+        self.gen_add_code_line("// Define custom structs" + (" (same layout as the enclosing namespace's - own types, so that argument-dependent lookup stays inside this namespace; init_* and close_grid are the enclosing namespace's)" if self.nested else ""))
         self.gen_add_code_lines(["template <typename T>", "struct robotModel {", "    T *d_XImats;", "    int *d_topology_helpers;", "};"])
         self.gen_add_code_lines(["template <typename T>", "struct gridData {",
                                  "    // GPU INPUTS", "    T *d_q_qd_u;", "    T *d_q_qd;", "    T *d_q;",
@@ -404,6 +413,66 @@ class GRiDCodeGenerator:
                                  "for(int i=0; i<" + str(MAX_STREAMS) + "; i++){gpuErrchk(hipStreamDestroy(streams[i]));} free(streams);"])
         self.gen_add_end_function()
 
+    def so_wide_lanes(self):
+        """Lane-group width of the nested `wide` instance that carries the second-order kernels (tuning so_lanes), or None."""
+        want = self.tuning["so_lanes"]
+        if self.nested or want == "off" or self.lanes_per_solve != 8 or not self.gen_idsva_so_available() or int(self.tuning["debug_stop"]) != 0:
+            return None
+        if want not in ("auto", 16):
+            raise ValueError("tuning['so_lanes'] must be auto, off or 16")
+        return 16
+
+    def _gen_library_body(self, use_thread_group=False, include_base_inertia=False, include_homogenous_transforms=False):
+        """Everything inside the namespace.  The nested `wide` instance (so_wide_lanes) emits the same body minus structs, init_* and close_grid."""
+        self.gen_add_constants_helpers(include_base_inertia, include_homogenous_transforms)
+        self.gen_spatial_algebra_helpers()
+        if self.tip_frame or self.branch_frame or self.gen_idsva_so_mode() is not None:  # (the second-order kernels use its cross products, 10-parameter inertias, Coriolis matrices)
+            self.gen_tip_frame_library()
+        if self.branch_frame:
+            self.gen_branch_frame_library()
+        self.gen_model_constant_table()
+        if not self.nested:
+            self.gen_init_topology_helpers()
+            self.gen_init_XImats(include_base_inertia, include_homogenous_transforms)
+            self.gen_init_robotModel()
+            self.gen_init_gridData()
+        self.gen_load_update_XImats_helpers(use_thread_group)
+        if self.tip_frame:
+            self.gen_tip_frame_components(use_thread_group)
+        elif self.branch_frame:
+            self.gen_branch_frame_components(use_thread_group)
+        # the dynamics algorithms on (and next to) the forward-dynamics-gradient path
+        self.gen_inverse_dynamics(use_thread_group)
+        self.gen_direct_minv(use_thread_group)
+        self.gen_forward_dynamics(use_thread_group)
+        self.gen_aba(use_thread_group)
+        self.gen_inverse_dynamics_gradient(use_thread_group)
+        if self.tip_frame:
+            self.gen_tip_frame_gradient(use_thread_group)
+        if self.branch_frame:
+            self.gen_forward_dynamics_gradient_inner_branch(use_thread_group)
+            if self.fd_stream_out:
+                self.gen_forward_dynamics_gradient_inner_branch_stream(use_thread_group)
+        self.gen_forward_dynamics_gradient(use_thread_group)
+        wide = self.so_wide_lanes()
+        if wide:
+            # second instance of the library for wider lane groups, in a nested namespace; the second-order host wrappers below launch ITS kernels
+            sub = GRiDCodeGenerator(self.robot, FILE_NAMESPACE="wide", DEBUG_MODE=self._ctor["DEBUG_MODE"], NEED_PRINT_MAT=self._ctor["NEED_PRINT_MAT"], COLS_PER_LANE=self._ctor["COLS_PER_LANE"],
+                                    tuning=dict(self._ctor["tuning"], min_lanes=wide, so_lanes="off"))
+            sub.nested, sub.parent_namespace, sub.indent_level = True, self.file_namespace, self.indent_level
+            sub.gen_add_func_doc("The same library for lane groups of %d lanes: what the second-order host wrappers (idsva_so_host, fdsva_so) and the C ABI launch" % wide,
+                                 ["half as many solves stage their 4 n^3 records per wave and the item loops of idsva_so spread over twice the lanes",
+                                  "init_* and close_grid are the enclosing namespace's (robotModel / gridData have the same layout here); launch its kernels with wide::GRID_LANES_PER_SOLVE lanes per solve"])
+            sub.gen_add_code_line("namespace wide {", True)
+            sub._gen_library_body(use_thread_group, include_base_inertia, include_homogenous_transforms)
+            sub.gen_add_end_control_flow()
+            self.code_str += sub.code_str
+            self.gen_add_code_line("#define GRID_SO_WIDE 1 // the second-order host wrappers launch the kernels of namespace wide (%d lanes per solve)" % wide)
+        self.gen_idsva_so(use_thread_group)
+        self.gen_fdsva_so(use_thread_group)
+        if not self.nested:
+            self.gen_init_close_grid()
+
     # ------------------------------------------------------------------ everything
     def gen_all_code(self, use_thread_group=False, include_base_inertia=False, include_homogenous_transforms=False, fixed_target_name=""):
         if use_thread_group:
@@ -467,38 +536,7 @@ class GRiDCodeGenerator:
         self.gen_add_code_line("")
         self.gen_add_func_doc("All functions are kept in this namespace")
         self.gen_add_code_line("namespace " + self.file_namespace + " {", True)
-        self.gen_add_constants_helpers(include_base_inertia, include_homogenous_transforms)
-        self.gen_spatial_algebra_helpers()
-        if self.tip_frame or self.branch_frame or self.gen_idsva_so_mode() is not None:  # (the second-order kernels use its cross products, 10-parameter inertias, Coriolis matrices)
-            self.gen_tip_frame_library()
-        if self.branch_frame:
-            self.gen_branch_frame_library()
-        self.gen_model_constant_table()
-        self.gen_init_topology_helpers()
-        self.gen_init_XImats(include_base_inertia, include_homogenous_transforms)
-        self.gen_init_robotModel()
-        self.gen_init_gridData()
-        self.gen_load_update_XImats_helpers(use_thread_group)
-        if self.tip_frame:
-            self.gen_tip_frame_components(use_thread_group)
-        elif self.branch_frame:
-            self.gen_branch_frame_components(use_thread_group)
-        # the dynamics algorithms on (and next to) the forward-dynamics-gradient path
-        self.gen_inverse_dynamics(use_thread_group)
-        self.gen_direct_minv(use_thread_group)
-        self.gen_forward_dynamics(use_thread_group)
-        self.gen_aba(use_thread_group)
-        self.gen_inverse_dynamics_gradient(use_thread_group)
-        if self.tip_frame:
-            self.gen_tip_frame_gradient(use_thread_group)
-        if self.branch_frame:
-            self.gen_forward_dynamics_gradient_inner_branch(use_thread_group)
-            if self.fd_stream_out:
-                self.gen_forward_dynamics_gradient_inner_branch_stream(use_thread_group)
-        self.gen_forward_dynamics_gradient(use_thread_group)
-        self.gen_idsva_so(use_thread_group)
-        self.gen_fdsva_so(use_thread_group)
-        self.gen_init_close_grid()
+        self._gen_library_body(use_thread_group, include_base_inertia, include_homogenous_transforms)
         self.gen_add_end_control_flow()
         with open(self.file_namespace + ".cuh", "w") as f:
             f.write(self.code_str)

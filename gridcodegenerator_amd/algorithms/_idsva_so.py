@@ -637,6 +637,11 @@ def gen_idsva_so_host(self, mode=0):
     self.gen_add_code_line("__host__")
     self.gen_add_code_line("void " + name + "(gridData<T> *hd_data, const robotModel<T> *d_robotModel, const T gravity, const int num_timesteps,")
     self.gen_add_code_line("                      const dim3 block_dimms, const dim3 thread_dimms" + ("" if compute_only else ", hipStream_t *streams") + ") {", True)
+    if self.so_wide_lanes():
+        self.gen_add_code_line("// (GRID_SO_WIDE) the kernels of the nested library for wider lane groups do the work; block_dimms may count lane groups of either width: the kernels grid-stride")
+        self.gen_add_code_line("wide::" + name + "<T, USE_QDD_FLAG>(reinterpret_cast<wide::gridData<T> *>(hd_data), reinterpret_cast<const wide::robotModel<T> *>(d_robotModel), gravity, num_timesteps, block_dimms, thread_dimms" + ("" if compute_only else ", streams") + "); // (same layouts)")
+        self.gen_add_end_function()
+        return
     self.gen_add_code_line("int stride_q_qd = 3*NUM_JOINTS;")
     self.gen_add_code_line("if (num_timesteps > grid_so_max_timesteps<T>()) {gpuErrchk(hipErrorInvalidValue); return;} // (beyond what init_gridData allocates for second-order records)")
     cnt = "" if single_call_timing else "num_timesteps*"

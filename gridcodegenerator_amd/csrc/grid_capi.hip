@@ -101,19 +101,28 @@ struct launch_cfg {
     dim3 grid, block;
     size_t lds;
 };
+// the second-order kernels: robots with 8-lane groups carry a second instance of the library for 16-lane groups (GRID_SO_WIDE, namespace grid::wide)
+#ifdef GRID_SO_WIDE
+namespace grid_so = grid::wide;
+#else
+namespace grid_so = grid;
+#endif
+
 template <typename T>
-static int make_launch(const grid_handle *h, int num_timesteps, int default_threads, int max_groups, int lds_per_solve, int out_per_solve, launch_cfg *cfg) {
+static int make_launch(const grid_handle *h, int num_timesteps, int default_threads, int max_groups, int lds_per_solve, int out_per_solve, launch_cfg *cfg,
+                       int lanes = grid::GRID_LANES_PER_SOLVE) {
     int threads = h->threads > 0 ? h->threads : default_threads;
+    if (threads < lanes) threads = lanes;  // (the second-order kernels of 8-lane robots run 16-lane groups: namespace wide)
     if (threads < grid::GRID_LANES_PER_SOLVE || threads > grid::GRID_MAX_THREADS)
         return fail_msg(hipErrorInvalidConfiguration, "threads per block out of range");
-    int gpb = threads / grid::GRID_LANES_PER_SOLVE;
+    int gpb = threads / lanes;
     if (gpb > max_groups) gpb = max_groups;  // (the kernels retire the lane groups beyond their cap)
     const size_t per_group = (size_t)(lds_per_solve + out_per_solve) * sizeof(T);
     if ((size_t)gpb * per_group > GRID_CU_LDS_BYTES) {
         // e.g. the 30-DoF robot in double precision: fewer solves per block than the block size suggests
         gpb = (int)(GRID_CU_LDS_BYTES / per_group);
         if (gpb < 1) return fail_msg(hipErrorInvalidConfiguration, "one solve of this robot does not fit the LDS of a CU in this precision");
-        threads = gpb * grid::GRID_LANES_PER_SOLVE;
+        threads = gpb * lanes;
     }
     int blocks = h->blocks > 0 ? h->blocks : (num_timesteps + gpb - 1) / gpb;
     if (blocks < 1) blocks = 1;
@@ -288,11 +297,11 @@ static int idsva_so_device(grid_handle *h, const T *d_q_qd_u, int stride, const 
     GRID_ON_DEVICE(h);
     if ((rc = ensure_typed<T>(h))) return rc;
     launch_cfg c;
-    if ((rc = make_launch<T>(h, N, grid::IDSVA_SO_SUGGESTED_THREADS, grid::IDSVA_SO_MAX_SOLVES_PER_BLOCK, grid::IDSVA_SO_LDS_PER_SOLVE, grid::IDSVA_SO_STAGE_PER_SOLVE, &c))) return rc;
+    if ((rc = make_launch<T>(h, N, grid_so::IDSVA_SO_SUGGESTED_THREADS, grid_so::IDSVA_SO_MAX_SOLVES_PER_BLOCK, grid_so::IDSVA_SO_LDS_PER_SOLVE, grid_so::IDSVA_SO_STAGE_PER_SOLVE, &c, grid_so::GRID_LANES_PER_SOLVE))) return rc;
     if (d_qdd) {
-        hipLaunchKernelGGL((grid::idsva_so_kernel<T>), c.grid, c.block, c.lds, (hipStream_t)stream, d_idsva_so, d_q_qd_u, stride, d_qdd, typed<T>(h).d_robotModel, gravity, N);
+        hipLaunchKernelGGL((grid_so::idsva_so_kernel<T>), c.grid, c.block, c.lds, (hipStream_t)stream, d_idsva_so, d_q_qd_u, stride, d_qdd, reinterpret_cast<const grid_so::robotModel<T> *>(typed<T>(h).d_robotModel), gravity, N);
     } else {
-        hipLaunchKernelGGL((grid::idsva_so_kernel<T>), c.grid, c.block, c.lds, (hipStream_t)stream, d_idsva_so, d_q_qd_u, stride, typed<T>(h).d_robotModel, gravity, N);
+        hipLaunchKernelGGL((grid_so::idsva_so_kernel<T>), c.grid, c.block, c.lds, (hipStream_t)stream, d_idsva_so, d_q_qd_u, stride, reinterpret_cast<const grid_so::robotModel<T> *>(typed<T>(h).d_robotModel), gravity, N);
     }
     GRID_TRY(hipGetLastError());
     return 0;
@@ -311,13 +320,13 @@ static int fdsva_so_device(grid_handle *h, const T *d_q_qd_u, int stride, int N,
     GRID_ON_DEVICE(h);
     if ((rc = ensure_typed<T>(h))) return rc;
     launch_cfg c;
-    if ((rc = make_launch<T>(h, N, grid::FDSVA_SO_SUGGESTED_THREADS, grid::FDSVA_SO_MAX_SOLVES_PER_BLOCK, grid::GRID_LDS_PER_SOLVE, grid::FDSVA_SO_STAGE_PER_SOLVE, &c))) return rc;
+    if ((rc = make_launch<T>(h, N, grid_so::FDSVA_SO_SUGGESTED_THREADS, grid_so::FDSVA_SO_MAX_SOLVES_PER_BLOCK, grid_so::GRID_LDS_PER_SOLVE, grid_so::FDSVA_SO_STAGE_PER_SOLVE, &c, grid_so::GRID_LANES_PER_SOLVE))) return rc;
 #if GRID_SO_DIRECT
     // the idsva_so tensors of a solve do not fit LDS: the kernel keeps them in the handle's d_idsva_so buffer
     if (N > so_capacity<T>(h)) return fail_msg(hipErrorInvalidValue, "num_timesteps exceeds the handle's second-order workspace (grid_second_order_capacity)");
-    hipLaunchKernelGGL((grid::fdsva_so_kernel<T>), c.grid, c.block, c.lds, (hipStream_t)stream, d_df2, typed<T>(h).hd_data->d_idsva_so, d_q_qd_u, stride, typed<T>(h).d_robotModel, gravity, N);
+    hipLaunchKernelGGL((grid_so::fdsva_so_kernel<T>), c.grid, c.block, c.lds, (hipStream_t)stream, d_df2, typed<T>(h).hd_data->d_idsva_so, d_q_qd_u, stride, reinterpret_cast<const grid_so::robotModel<T> *>(typed<T>(h).d_robotModel), gravity, N);
 #else
-    hipLaunchKernelGGL((grid::fdsva_so_kernel<T>), c.grid, c.block, c.lds, (hipStream_t)stream, d_df2, d_q_qd_u, stride, typed<T>(h).d_robotModel, gravity, N);
+    hipLaunchKernelGGL((grid_so::fdsva_so_kernel<T>), c.grid, c.block, c.lds, (hipStream_t)stream, d_df2, d_q_qd_u, stride, reinterpret_cast<const grid_so::robotModel<T> *>(typed<T>(h).d_robotModel), gravity, N);
 #endif
     GRID_TRY(hipGetLastError());
     return 0;

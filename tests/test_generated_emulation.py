@@ -239,6 +239,27 @@ def test_emulated_idsva_so_subtree_mapping_variant(name, golden):
     assert np.array_equal(outs[0], outs[1])
 
 
+def test_emulated_second_order_narrow_and_wide_lane_groups_agree(golden):
+    """Robots with 8-lane groups carry a second instance of the library for 16-lane groups (namespace grid::wide, tuning so_lanes) whose kernels the
+    second-order entry points launch; tuning so_lanes = off keeps the 8-lane kernels.  Same arithmetic per entry, different lanes execute it."""
+    g = golden("iiwa14")
+    wide = emu_library("iiwa14", max_timesteps=8)
+    narrow = emu_library("iiwa14", max_timesteps=8, tuning={"so_lanes": "off"})
+    n, N = wide.n, 3
+    x = np.ascontiguousarray(np.hstack([g["q"], g["qd"], g["u"]]).astype(np.float32)[:N])
+    qdd = np.ascontiguousarray(g["qdd"].astype(np.float32)[:N])
+    outs = []
+    for lib in (wide, narrow):
+        a = np.full((N, 4 * n ** 3), np.nan, np.float32)
+        b = np.full((N, 4 * n ** 3), np.nan, np.float32)
+        lib.idsva_so_device(x, qdd, N, a)
+        lib.fdsva_so_device(x, N, b)
+        assert np.isfinite(a).all() and np.isfinite(b).all()
+        outs.append((a, b))
+    assert np.array_equal(outs[0][0], outs[1][0])
+    assert np.abs(outs[0][1] - outs[1][1]).max() <= 1e-6 * np.abs(outs[1][1]).max()
+
+
 @pytest.mark.parametrize("name,n", [("mixed5", 5)])
 def test_emulated_second_order_is_refused_where_it_is_not_emitted(name, n, libs):
     """Robots with prismatic joints are outside the second-order scope: hipErrorNotSupported."""
