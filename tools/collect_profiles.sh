@@ -23,4 +23,5 @@ python3 tools/bench_idsva_so.py hyq 4096 >> $O/so_bench.jsonl 2> /dev/null || ex
 python3 tools/bench_idsva_so.py atlas 1024 >> $O/so_bench.jsonl 2> /dev/null || exit 1
 python3 tests/tools/bench_components.py > $O/components.jsonl 2> /dev/null || exit 1
 python3 tools/bench_robots.py > $O/robots.jsonl 2> /dev/null || exit 1
+for cfg in "atlas 16384" "hyq 4096" "iiwa14 1024" "iiwa14 16384"; do python3 tools/bench_kernels.py $cfg >> $O/kernels.jsonl 2> /dev/null || exit 1; done
 echo done

@@ -36,7 +36,7 @@ def write_sq(path, head, out):
 ks = glob.glob(base + "trace/**/*kernel_stats.csv", recursive=True)[0]
 shutil.copy(ks, os.path.join(P, tag + "_kernel_stats.csv"))
 shutil.copy(base + "bench.json", os.path.join(P, tag + "_bench_n1.json"))
-for extra in ("components.jsonl", "robots.jsonl", "so_bench.jsonl"):
+for extra in ("components.jsonl", "robots.jsonl", "so_bench.jsonl", "kernels.jsonl"):
     if os.path.exists(base + extra):
         shutil.copy(base + extra, os.path.join(P, tag + "_" + extra))
 bench = json.loads(open(base + "bench.json").read().strip().splitlines()[-1])
