@@ -27,8 +27,8 @@ TUNING_DEFAULTS = {
     "so_mapping": "balanced",   # balanced | subtree: work distribution of the idsva_so main loops (algorithms/_idsva_so.py: gen_idsva_so_items)
     "min_lanes": 8,             # smallest lane group (8 | 16 | 32 | 64): wider groups than the joint count needs leave lanes idle in the first-order kernels but
                                 # give the item loops of the second-order kernels more lanes per solve (and fewer solves' staging per wave)
-    "so_lanes": "auto",         # auto | off | 16: lane-group width of the second-order KERNELS.  Robots with 8-lane groups (n <= 8) get a second instance of the
-                                # library for 16-lane groups in the nested namespace `wide` and idsva_so_host / fdsva_so (and the C ABI) launch its kernels:
+    "so_lanes": "auto",         # auto | off | 16 | 32: lane-group width of the second-order KERNELS.  Robots with 8- or 16-lane groups get a second instance of the
+                                # library for groups twice as wide in the nested namespace `wide` and idsva_so_host / fdsva_so (and the C ABI) launch its kernels:
                                 # half the staging per wave, twice the lanes in the item loops (7-DoF arm, 65 536 solves: idsva_so 289 -> 195 us)
     "so_direct": "auto",        # auto | True: second-order kernels write their 4 n^3 record straight to global memory instead of staging it in LDS
                                 # (auto = only where the record does not fit LDS, algorithms/_idsva_so.py: gen_idsva_so_direct)
@@ -416,11 +416,15 @@ class GRiDCodeGenerator:
     def so_wide_lanes(self):
         """Lane-group width of the nested `wide` instance that carries the second-order kernels (tuning so_lanes), or None."""
         want = self.tuning["so_lanes"]
-        if self.nested or want == "off" or self.lanes_per_solve != 8 or not self.gen_idsva_so_available() or int(self.tuning["debug_stop"]) != 0:
+        if self.nested or want == "off" or self.lanes_per_solve > 16 or not self.gen_idsva_so_available() or int(self.tuning["debug_stop"]) != 0:
             return None
-        if want not in ("auto", 16):
-            raise ValueError("tuning['so_lanes'] must be auto, off or 16")
-        return 16
+        if want == "auto":
+            # measured (gpurun_out/r3e, r3g): 7-DoF arm 8 -> 16 lanes idsva_so 289 -> 195 us per 65 536 solves (32 lanes: 298); quadruped 16 -> 32 lanes
+            # 414 -> 275 us per 16 384, 12-DoF tree 578 -> 431 (their 28 KB records leave ONE wave per CU at 4 solves per wave)
+            return 2 * self.lanes_per_solve
+        if want not in (16, 32) or want <= self.lanes_per_solve:
+            raise ValueError("tuning['so_lanes'] must be auto, off, or 16 / 32 and wider than the robot's lane groups")
+        return want
 
     def _gen_library_body(self, use_thread_group=False, include_base_inertia=False, include_homogenous_transforms=False):
         """Everything inside the namespace.  The nested `wide` instance (so_wide_lanes) emits the same body minus structs, init_* and close_grid."""
