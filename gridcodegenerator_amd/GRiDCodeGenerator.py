@@ -418,10 +418,16 @@ class GRiDCodeGenerator:
         want = self.tuning["so_lanes"]
         if self.nested or want == "off" or self.lanes_per_solve > 16 or not self.gen_idsva_so_available() or int(self.tuning["debug_stop"]) != 0:
             return None
+        if hasattr(self, "_so_wide_cache"):
+            return self._so_wide_cache
         if want == "auto":
-            # measured (gpurun_out/r3e, r3g): 7-DoF arm 8 -> 16 lanes idsva_so 289 -> 195 us per 65 536 solves (32 lanes: 298); quadruped 16 -> 32 lanes
-            # 414 -> 275 us per 16 384, 12-DoF tree 578 -> 431 (their 28 KB records leave ONE wave per CU at 4 solves per wave)
-            return 2 * self.lanes_per_solve
+            # the wider instance must run the same second-order form (a 12-joint chain would fall from the tip-frame chain form to the base-frame tree
+            # form at 32 lanes: 10x the fp32 error for no gain)
+            probe = GRiDCodeGenerator(self.robot, COLS_PER_LANE=self._ctor["COLS_PER_LANE"], tuning=dict(self._ctor["tuning"], min_lanes=2 * self.lanes_per_solve, so_lanes="off"))
+            self._so_wide_cache = 2 * self.lanes_per_solve if probe.gen_idsva_so_mode() == self.gen_idsva_so_mode() else None
+            return self._so_wide_cache
+        # measured (gpurun_out/r3e, r3g): 7-DoF arm 8 -> 16 lanes idsva_so 289 -> 195 us per 65 536 solves (32 lanes: 298); quadruped 16 -> 32 lanes
+        # 414 -> 275 us per 16 384, 12-DoF tree 578 -> 431 (their 28 KB records leave ONE wave per CU at 4 solves per wave)
         if want not in (16, 32) or want <= self.lanes_per_solve:
             raise ValueError("tuning['so_lanes'] must be auto, off, or 16 / 32 and wider than the robot's lane groups")
         return want

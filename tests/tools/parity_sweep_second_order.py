@@ -13,7 +13,7 @@ from oracle.rbd_oracle import Oracle
 
 for name in (sys.argv[1:] or ["iiwa14", "arm6", "chain12"]):
     robot = RobotModel.from_fixture(name); n = robot.n; model = DuckRobot(robot); orc = Oracle(robot)
-    N = 32768 if n <= 7 else 4096
+    N = 32768 if n <= 7 else (4096 if n <= 16 else 1024)  # (30 joints: 432 KB per record, the handle's second-order buffers hold 2 485 solves)
     lib = load(name, max_timesteps=N)
     rng = np.random.default_rng(5)
     x = np.hstack([rng.uniform(-np.pi, np.pi, (N, n)), rng.uniform(-2, 2, (N, n)), rng.uniform(-10, 10, (N, n))]).astype(np.float32)
