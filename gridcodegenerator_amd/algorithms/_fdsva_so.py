@@ -82,13 +82,12 @@ def gen_fdsva_so_inner(self, use_thread_group=False):
     self.gen_add_code_line("void fdsva_so_inner(T *df2, const T *s_idsva_so, const T *s_Minv, const T *s_df_du, const int lane, const bool active) {", True)
     lines = (_ROLLED if n > 12 else """
 const T *tqq = s_idsva_so, *tvv = s_idsva_so + @N3@, *tvq = s_idsva_so + 2*@N3@, *dM = s_idsva_so + 3*@N3@;
-const int j = (lane < @N@) ? lane : 0;
-const bool own = active && (lane < @N@);
+@SPLIT@
 T fq_j[@N@], fv_j[@N@], mi_j[@N@]; // column j of df/dq and of df/dqd, row j of M^-1
 #pragma unroll
 for (int p = 0; p < @N@; p++) { fq_j[p] = s_df_du[j*@N@ + p]; fv_j[p] = s_df_du[(@N@ + j)*@N@ + p]; mi_j[p] = s_Minv[j*@LD@ + p]; }
 #pragma unroll 1
-for (int k = 0; k < @N@; k++) {
+for (int k = @K0@; k < @N@; k += @KSTEP@) {
     T fq_k[@N@];
     #pragma unroll
     for (int p = 0; p < @N@; p++) { fq_k[p] = s_df_du[k*@N@ + p]; }
@@ -112,7 +111,13 @@ for (int k = 0; k < @N@; k++) {
         }
     }
 }
-""").replace("@N3@", str(n3)).replace("@N@", str(n)).replace("@LD@", str(ld))
+""")
+    G = self.lanes_per_solve
+    if n <= 12 and G // 2 >= n:  # lane groups at least twice as wide as the robot has joints (the `wide` instances): the two halves of the group take alternate k
+        lines = lines.replace("@SPLIT@", "const int jl = lane %% %d, kh = lane / %d; // joint and k parity of this lane\nconst int j = (jl < @N@) ? jl : 0;\nconst bool own = active && (jl < @N@);" % (G // 2, G // 2)).replace("@K0@", "kh").replace("@KSTEP@", "2")
+    else:
+        lines = lines.replace("@SPLIT@", "const int j = (lane < @N@) ? lane : 0;\nconst bool own = active && (lane < @N@);").replace("@K0@", "0").replace("@KSTEP@", "1")
+    lines = lines.replace("@N3@", str(n3)).replace("@N@", str(n)).replace("@LD@", str(ld))
     for line in lines.strip("\n").split("\n"):
         self.gen_add_code_line(line)
     self.gen_add_end_function()

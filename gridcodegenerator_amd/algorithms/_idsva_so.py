@@ -76,8 +76,17 @@ def gen_idsva_so_lds_layout(self):
     if (sl // 4) % 2 == 0:
         sl += 4
     stage = 0 if self.gen_idsva_so_direct() else 4 * n * n * n
-    threads = 64
-    while threads > G and (threads // G) * (sl + stage) * 4 > 150 * 1024:
+    # block size: full waves unless fewer lane groups per block let at least a quarter more solves be resident on a CU (quadruped, 32-lane groups, 16 384
+    # solves: one solve per block 231 us, two 274; 6-DoF arm, 16-lane groups, 65 536 solves: four per block 135 us, three - 8 % more resident - 180)
+    per = (sl + stage) * 4
+    resident = lambda g_: min((155 * 1024 // (g_ * per)) * g_, 16 * min(g_, max(1, 64 // G)))  # (LDS capacity, and at most 16 waves per CU)
+    best_g = max(1, 64 // G)
+    for g_ in range(max(1, 32 // G), best_g):
+        if 4 * resident(g_) >= 5 * resident(best_g):
+            best_g = g_
+            break
+    threads = best_g * G
+    while threads > G and (threads // G) * per > 150 * 1024:
         threads -= G
     return sl, scratch, stage, threads
 
