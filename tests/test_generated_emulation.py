@@ -340,17 +340,19 @@ def _random_tree_description(seed, n):
     return dict(name="rnd%d" % seed, base_link="base", joints=joints)
 
 
-@pytest.mark.parametrize("seed,n", [(16, 8), (13, 7), (1, 9), (2, 14), (3, 20), (4, 27)])  # (8-lane groups with two tree levels / two components, ..., 32-lane groups)
-def test_emulated_random_trees_on_the_branch_frame_path(seed, n):
+@pytest.mark.parametrize("seed,n,tuning", [(16, 8, {}), (13, 7, {}), (1, 9, {}), (2, 14, {}), (3, 20, {}), (4, 27, {}),  # (8-lane groups with two tree levels / two components, ..., 32-lane groups)
+                                           (58, 20, {"factor_split": "branch", "stream_out": True}), (61, 11, {"factor_split": "branch"})])  # (three / four tree levels)
+def test_emulated_random_trees_on_the_branch_frame_path(seed, n, tuning):
     """Generator robustness: random tree topologies (nesting depth, component shapes, lane packing all vary) through the unchanged
-    generated header on the branch-frame path, checked against the C oracle (itself pinned by the reference's goldens)."""
+    generated header on the branch-frame path, checked against the C oracle (itself pinned by the reference's goldens); the last cases force the
+    factorisation split by branch (Schur complements handed up over three and four tree levels) and the half-image form of the kernel."""
     from gridcodegenerator_amd import GRiDCodeGenerator
     from oracle.rbd_oracle import Oracle
 
     robot = RobotModel(_random_tree_description(seed, n))
-    gen = GRiDCodeGenerator(robot)
+    gen = GRiDCodeGenerator(robot, tuning=tuning)
     assert gen.branch_frame or gen.tip_frame, "random tree fell back to the column walk"
-    lib = emu_library(robot, max_timesteps=16)
+    lib = emu_library(robot, max_timesteps=16, tuning=dict({"so_lanes": "off"}, **tuning))
     rng = np.random.default_rng(100 + seed)
     N = 5
     x = np.hstack([rng.uniform(-np.pi, np.pi, (N, n)), rng.uniform(-2, 2, (N, n)), rng.uniform(-10, 10, (N, n))]).astype(np.float32)
