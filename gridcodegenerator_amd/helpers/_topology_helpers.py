@@ -75,6 +75,13 @@ def gen_lds_layout(self):
     want = self.tuning["stream_out"]
     self.fd_stream_out = False
     if getattr(self, "branch_frame", False) and want is not False and (n * n) % 4 == 0 and int(self.tuning["debug_stop"]) == 0 and not self.tuning["out_half"]:
+        from ..algorithms._branch_frame_gradient import branch_spare_in_image
+        if branch_spare_in_image(self, 2 * n * n) != branch_spare_in_image(self, n * n):
+            # (the slice above was sized for spare path records inside a full image; a half image of this small robot cannot take them)
+            if want is True:
+                raise NotImplementedError("stream_out: the half image of this robot is too small for the spare path records of the frame chain")
+            want = False
+    if getattr(self, "branch_frame", False) and want is not False and (n * n) % 4 == 0 and int(self.tuning["debug_stop"]) == 0 and not self.tuning["out_half"]:
         spw = 64 // self.lanes_per_solve
         park = _pad4(n * max(len(s_) for s_ in self.branch_plan["shapes"]))  # every lane's dc/dqd column, rows of its component
         tot2 = off["FD_TOTAL"] + park
