@@ -49,7 +49,7 @@ TUNING_DEFAULTS = {
                                 # evaluated about the origin of this joint instead of the tip (fp32 accuracy); auto = L // 2 for L >= 5
 }
 TUNING_ABLATION = {
-    "debug_stop": 0,            # truncate the kernel after a phase / cycle stamps (tools/prof_ablation.sh, tools/phase_stamps.py)
+    "debug_stop": 0,            # truncate the kernel after a phase / cycle stamps (tools/prof_ablation.sh, tools/phase_stamps.py); 21 = tip-frame inner without its frame chain
     "no_pins": False,           # drop the register pins
     "no_wave_barrier": False,   # drop the wave barrier of grid_wave_sync (fences only)
     "out_half": False,          # timing experiment: the output image of a solve overlaps its neighbour's (half the staging LDS, wrong results): what would more resident waves buy?

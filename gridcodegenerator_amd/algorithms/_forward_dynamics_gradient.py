@@ -50,7 +50,7 @@ def gen_forward_dynamics_gradient_inner_python(self, use_thread_group=False, use
         self.gen_add_end_control_flow()
         self.gen_add_end_control_flow()
         return
-    if self.tip_frame and stop in (0, 5, 6, 7, 20):  # serial revolute chains: everything after the X update is one fused inner in the tip link's frame
+    if self.tip_frame and stop in (0, 5, 6, 7, 20, 21):  # serial revolute chains: everything after the X update is one fused inner in the tip link's frame
         self.gen_forward_dynamics_gradient_inner_tip_function_call(use_thread_group, use_qdd_Minv_input, s_df_du_name)
         return
     if stop == 1:

@@ -569,8 +569,11 @@ def gen_forward_dynamics_gradient_inner_tip(self, use_thread_group=False, use_qd
     L = self.tip_L
     bf = (not use_qdd_Minv_input) and self.tip_jB is not None
     RS = self.tip_rec if not use_qdd_Minv_input else 16  # values per hand-off record
-    for i in range(L - 1, -1, -1):
-        _chain_step(self, i, "s_G" if chain_lds else None, base_family=bf)
+    if self.tuning["debug_stop"] == 21:  # timing ablation (wrong results): no frame chain at all - what is the walk worth?
+        self.gen_add_code_line("gvec[0] = gvec[1] = static_cast<T>(0); gvec[2] = gravity; // (ablation: every frame is the identity)")
+    else:
+        for i in range(L - 1, -1, -1):
+            _chain_step(self, i, "s_G" if chain_lds else None, base_family=bf)
     if chain_lds:
         self.gen_add_sync(use_thread_group)
         self.gen_add_code_line("if (lane < %d) { // this lane's own frame (lanes without a joint keep the identity; their link constants are zero)" % (n - 1), True)
