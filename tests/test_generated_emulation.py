@@ -260,6 +260,26 @@ def test_emulated_second_order_narrow_and_wide_lane_groups_agree(golden):
     assert np.abs(outs[0][1] - outs[1][1]).max() <= 1e-6 * np.abs(outs[1][1]).max()
 
 
+def test_emulated_second_order_direct_form_on_a_chain(golden):
+    """tuning so_direct = True: the second-order kernels write their records straight to global memory and fdsva_so reads the idsva_so tensors back from
+    the handle's workspace (what the 30-DoF humanoid runs by necessity), here forced onto the 7-DoF arm's chain form: same values as the LDS-staged form."""
+    g = golden("iiwa14")
+    staged = emu_library("iiwa14", max_timesteps=8, tuning={"so_lanes": "off"})
+    direct = emu_library("iiwa14", max_timesteps=8, tuning={"so_lanes": "off", "so_direct": True})
+    n, N = staged.n, 5  # (five solves on 8-lane groups and 64-thread blocks: a ragged last wave)
+    x = np.ascontiguousarray(np.hstack([g["q"], g["qd"], g["u"]]).astype(np.float32)[:N])
+    qdd = np.ascontiguousarray(g["qdd"].astype(np.float32)[:N])
+    outs = []
+    for lib in (staged, direct):
+        a = np.full((N, 4 * n ** 3), np.nan, np.float32)
+        b = np.full((N, 4 * n ** 3), np.nan, np.float32)
+        lib.idsva_so_device(x, qdd, N, a)
+        lib.fdsva_so_device(x, N, b)
+        assert np.isfinite(a).all() and np.isfinite(b).all()
+        outs.append((a, b))
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
+
+
 @pytest.mark.parametrize("name,n", [("mixed5", 5)])
 def test_emulated_second_order_is_refused_where_it_is_not_emitted(name, n, libs):
     """Robots with prismatic joints are outside the second-order scope: hipErrorNotSupported."""
