@@ -100,7 +100,7 @@ def gen_branch_frame_plan(self):
         shape_of[cb] = shapes.index(sig)
     D = max(len(p_) for p_ in paths)
     maxchild = max([len(k_) for k_ in kids] + [0])
-    row_len = (24 + D + max(maxchild, 1) + 3 * D + 3) // 4 * 4  # (header | path codes | child branches | joint offsets along the path)
+    row_len = (24 + D + max(maxchild, 1) + 3 * D + 3) // 4 * 4 + 4  # (header | path codes | child branches | joint offsets along the path | parent branch slot, pad)
     # compact (tree-sparse) storage of M and of its factors: column k holds the entries of its ancestors (ascending) and then the diagonal
     mstart, at = [0] * n, 0
     for j in range(n):
@@ -250,9 +250,130 @@ def _emit_factor_by_branch(self, P, with_rhs, R32, use_thread_group, ptr):
         self.gen_add_sync(use_thread_group)
 
 
+def branch_chain_scan(self):
+    """tuning branch_chain: walk | scan | auto.  Measured per 16 384 solves: 12-joint chain (one branch, D = 12) walk 42.4 us, scan 38.7; 30-DoF humanoid
+    (two tree levels, D = 10) 86.4 / 91.7; 12-DoF tree (three levels, D = 6) 30.7 / 32.5 - the scan pays for long single branches only (the level phases
+    and the cross-lane broadcasts of the tree cost more than the shorter walks save)."""
+    want = self.tuning["branch_chain"]
+    if want not in ("walk", "scan", "auto"):
+        raise ValueError("tuning['branch_chain'] must be walk, scan or auto")
+    P = self.branch_plan
+    return want == "scan" or (want == "auto" and P["maxlevel"] == 0 and P["D"] >= 10)
+
+
+def _emit_chain_scan(self, P, H, RL, bfam, kin, use_thread_group, ptr):
+    """Frames of the branch-frame path without the per-lane walk (tuning branch_chain = scan): a log-step DPP scan of rigid transforms over the lanes of a
+    branch gives every lane the pose of its own link in the branch frame; the pose of the parent branch's frame follows from the branch's first lane;
+    the joint axes along the root path are written by the lanes that own them and, tree level by tree level, re-expressed by the child branches (one
+    ancestor per lane) - instead of every lane stepping through all D path joints."""
+    A = self.gen_add_code_line
+    D, maxLb, maxlevel, maxchild = P["D"], P["maxLb"], P["maxlevel"], P["maxchild"]
+    ro = H + D + max(maxchild, 1)
+    one = "static_cast<T>(1)"
+    A("{", True)
+    A("const bool has_next = active && (pos + 1 < Lb); // a joint of the same branch follows towards the tip (ids are consecutive inside a branch)")
+    A("const int jn = has_next ? jid + 1 : js, io = active ? own : 0, inx = has_next ? own - 1 : 0;")
+    A("T Eo[9], En[9], ro_[3], rn_[3]; // E(q) and frame origin (in the parent's coordinates) of this lane's joint and of the next one")
+    A("#pragma unroll")
+    A("for (int r = 0; r < 9; r++) { Eo[r] = s_X[GRID_X_STRIDE*js + r]; En[r] = s_X[GRID_X_STRIDE*jn + r]; }")
+    A("#pragma unroll")
+    A("for (int r = 0; r < 3; r++) { ro_[r] = d_L[%d + 3*io + r]; rn_[r] = d_L[%d + 3*inx + r]; }" % (ro, ro))
+    A("const int pslot = static_cast<int>(d_L[%d]); // slot of the parent branch" % (RL - 4))
+    self.gen_add_sync(use_thread_group)
+    A("// (every lane has read X(q): its storage is free from here on)  pose of this link relative to the next one: (E_next, -E_next r_next); identity on tip lanes")
+    A("T R[9], p[3];")
+    A("#pragma unroll")
+    A("for (int r = 0; r < 9; r++) { R[r] = has_next ? En[r] : ((r %% 4 == 0) ? %s : Z); }" % one)
+    A("#pragma unroll")
+    A("for (int r = 0; r < 3; r++) { p[r] = has_next ? -(En[3*r]*rn_[0] + En[3*r + 1]*rn_[1] + En[3*r + 2]*rn_[2]) : Z; }")
+    for k in [k_ for k_ in (1, 2, 4, 8) if k_ < maxLb]:
+        A("{ // suffix scan over the lanes of the branch, step %d: (R, p) <- (R, p)[lane + %d] o (R, p)" % (k, k), True)
+        A("T Ra[9], pa[3], Rn[9], pn[3];")
+        A("#pragma unroll")
+        A("for (int r = 0; r < 9; r++) { Ra[r] = grid_lane_above<%d>(R[r]); }" % k)
+        A("#pragma unroll")
+        A("for (int r = 0; r < 3; r++) { pa[r] = grid_lane_above<%d>(p[r]); }" % k)
+        A("const bool ok = active && (pos + %d < Lb);" % k)
+        A("#pragma unroll")
+        A("for (int r = 0; r < 3; r++) {", True)
+        A("#pragma unroll")
+        A("for (int c = 0; c < 3; c++) { Rn[3*r + c] = Ra[3*r]*R[c] + Ra[3*r + 1]*R[3 + c] + Ra[3*r + 2]*R[6 + c]; }")
+        A("pn[r] = pa[r] + Ra[3*r]*p[0] + Ra[3*r + 1]*p[1] + Ra[3*r + 2]*p[2];")
+        self.gen_add_end_control_flow()
+        A("#pragma unroll")
+        A("for (int r = 0; r < 9; r++) { R[r] = ok ? Rn[r] : R[r]; }")
+        A("#pragma unroll")
+        A("for (int r = 0; r < 3; r++) { p[r] = ok ? pn[r] : p[r]; }")
+        self.gen_add_end_control_flow()
+    A("#pragma unroll")
+    A("for (int r = 0; r < 9; r++) { myR[r] = R[r]; }")
+    A("#pragma unroll")
+    A("for (int r = 0; r < 3; r++) { myp[r] = p[r]; }")
+    A("// pose of the parent branch's frame (the frame of the link this branch hangs off) in the branch frame: the first lane's pose composed with its own joint")
+    A("const int l0 = lane - pos; // first lane of this lane's branch")
+    A("{", True)
+    A("T cR[9], cp[3];")
+    A("#pragma unroll")
+    A("for (int r = 0; r < 3; r++) {", True)
+    A("#pragma unroll")
+    A("for (int c = 0; c < 3; c++) { cR[3*r + c] = R[3*r]*Eo[c] + R[3*r + 1]*Eo[3 + c] + R[3*r + 2]*Eo[6 + c]; }")
+    self.gen_add_end_control_flow()
+    A("#pragma unroll")
+    A("for (int r = 0; r < 3; r++) { cp[r] = p[r] - (cR[3*r]*ro_[0] + cR[3*r + 1]*ro_[1] + cR[3*r + 2]*ro_[2]); }")
+    A("#pragma unroll")
+    A("for (int r = 0; r < 9; r++) { TR[r] = __shfl(cR[r], l0, GRID_LANES_PER_SOLVE); }")
+    A("#pragma unroll")
+    A("for (int r = 0; r < 3; r++) { Tp[r] = __shfl(cp[r], l0, GRID_LANES_PER_SOLVE); }")
+    self.gen_add_end_control_flow()
+    if bfam:
+        A("{ const int lB = (active && iB >= 0) ? l0 + Lb - 1 - iB : lane; // the lane of the branch's middle joint")
+        A("  pB[0] = __shfl(myp[0], lB, GRID_LANES_PER_SOLVE); pB[1] = __shfl(myp[1], lB, GRID_LANES_PER_SOLVE); pB[2] = __shfl(myp[2], lB, GRID_LANES_PER_SOLVE);")
+        A("  if (!(active && iB >= 0)) { pB[0] = pB[1] = pB[2] = Z; } }")
+    A("T *s_Gh = %s; // branch records: free until the composites are handed over (here: gravity direction per branch)" % ptr("G"))
+    A("(void)s_Gh; (void)pslot;")
+    for lv in range(maxlevel + 1):
+        A("if (active && level == %d) { // tree level %d: joint axes along the root path, in this branch's frame" % (lv, lv), True)
+        if kin:
+            if lv == 0:
+                A("gvec[0] = gravity*TR[2]; gvec[1] = gravity*TR[5]; gvec[2] = gravity*TR[8]; // base acceleration (0,0,g) in this branch's coordinates")
+            else:
+                A("{ const T *gp = &s_Gh[28*pslot];")
+                A("  #pragma unroll")
+                A("  for (int r = 0; r < 3; r++) { gvec[r] = TR[3*r]*gp[0] + TR[3*r + 1]*gp[1] + TR[3*r + 2]*gp[2]; } }")
+            if lv < maxlevel:
+                A("if (pos == 0) { s_Gh[28*slot] = gvec[0]; s_Gh[28*slot + 1] = gvec[1]; s_Gh[28*slot + 2] = gvec[2]; }")
+        A("{ // this lane's own joint")
+        A("  const int ax = static_cast<int>(Lc[11]); T w[3];")
+        A("  #pragma unroll")
+        A("  for (int r = 0; r < 3; r++) { w[r] = (ax == 0) ? myR[3*r] : ((ax == 1) ? myR[3*r + 1] : myR[3*r + 2]); }")
+        A("  T *rec = &s_Sp[6*own];")
+        A("  rec[0] = w[0]; rec[1] = w[1]; rec[2] = w[2];")
+        A("  rec[3] = myp[1]*w[2] - myp[2]*w[1]; rec[4] = myp[2]*w[0] - myp[0]*w[2]; rec[5] = myp[0]*w[1] - myp[1]*w[0]; }")
+        if lv > 0:
+            A("#pragma unroll 1")
+            A("for (int k = pos; k < plen - Lb; k += Lb) { // the ancestors beyond the branch: the parent branch's records, re-expressed (one per lane and trip)", True)
+            A("const T *src = &s_SP[%d*pslot + 6*k]; T *dst = &s_Sp[6*(Lb + k)];" % (6 * D))
+            A("T w[3], mo[3];")
+            A("#pragma unroll")
+            A("for (int r = 0; r < 3; r++) { w[r] = TR[3*r]*src[0] + TR[3*r + 1]*src[1] + TR[3*r + 2]*src[2]; mo[r] = TR[3*r]*src[3] + TR[3*r + 1]*src[4] + TR[3*r + 2]*src[5]; }")
+            A("dst[0] = w[0]; dst[1] = w[1]; dst[2] = w[2];")
+            A("dst[3] = mo[0] + Tp[1]*w[2] - Tp[2]*w[1]; dst[4] = mo[1] + Tp[2]*w[0] - Tp[0]*w[2]; dst[5] = mo[2] + Tp[0]*w[1] - Tp[1]*w[0];")
+            self.gen_add_end_control_flow()
+        A("#pragma unroll 1")
+        A("for (int k = plen + pos; k < %d; k += Lb) { // zero beyond the root" % D, True)
+        A("#pragma unroll")
+        A("for (int r = 0; r < 6; r++) { s_Sp[6*k + r] = Z; }")
+        self.gen_add_end_control_flow()
+        self.gen_add_end_control_flow()
+        self.gen_add_sync(use_thread_group)
+    if not kin:
+        A("(void)gvec;")
+    self.gen_add_end_control_flow()
+
+
 def gen_branch_frame_constants(self):
     """Table rows appended to grid_model_constants: one row per lane
-    [Ic (6) | c (3) | m | damping | axis | joint id | pos | branch length | level | branch slot | component base | shape | path length | factor base of the component | start of the joint's column in the compact M | path step of the branch's base-origin joint (-1: none) | 1 if this lane's column of M uses the base family |
+    [(last quad of the row: slot of the parent branch) Ic (6) | c (3) | m | damping | axis | joint id | pos | branch length | level | branch slot | component base | shape | path length | factor base of the component | start of the joint's column in the compact M | path step of the branch's base-origin joint (-1: none) | 1 if this lane's column of M uses the base family |
      path codes (4*joint + axis, tip -> root, -1 = none) x D | child branch slots (-1 = none) x maxchild |
      origin of every path joint's frame in its parent's coordinates x D (so that no table read depends on another one)]."""
     m = self.model
@@ -298,6 +419,7 @@ def gen_branch_frame_constants(self):
         for i, pj in enumerate(P["paths"][b]):
             r = self.gen_tip_frame_joint_offset(pj)
             row[ro + 3 * i:ro + 3 * i + 3] = [float(r[0]), float(r[1]), float(r[2])]
+        row[P["row_len"] - 4] = float(P["pb"][b])  # slot of the parent branch (-1: the branch hangs off the base)
         rows += row
     return rows
 
@@ -524,7 +646,7 @@ def _emit_branch_inner(self, mode, use_thread_group=False):
     zero = {"fdgrad": ("s_df_du", n * n if stream else 2 * n * n), "idgrad": ("s_dc_du", 2 * n * n), "minv": ("s_Minv", n * ld)}.get(mode)
     A("grid_wave_sync();")
     spare_in_image = zero is not None and branch_spare_in_image(self, zero[1])
-    lanes_head = (6 * D + 3) // 4 if spare_in_image else 0  # quads at the head of the image that take the spare path records of the frame chain
+    lanes_head = (6 * D + 3) // 4 if (spare_in_image and not branch_chain_scan(self)) else 0  # quads at the head of the image that take the spare path records of the frame chain
     if zero is not None:
         A("// zero image of the result (unrelated joints, and rows outside the component of a column, stay exactly zero)")
         A("for (int e = lane + %d; e < %d; e += %d) {" % (lanes_head, zero[1] // 4, lanes), True)
@@ -541,69 +663,73 @@ def _emit_branch_inner(self, mode, use_thread_group=False):
     A("T myR[9], myp[3], TR[9], Tp[3], gvec[3] = {Z, Z, Z};")
     if bfam:
         A("T pB[3] = {Z, Z, Z}; // second reference point: the frame origin of the branch's middle joint, in the branch frame")
-    A("{", True)
-    ro = H + D + max(maxchild, 1)
-    A("T rj[%d][3]; // origins of the path joints' frames in their parents' coordinates: all table reads issued before the first use" % D)
-    for i in range(D - 1):
-        A("rj[%d][0] = d_L[%d]; rj[%d][1] = d_L[%d]; rj[%d][2] = d_L[%d];" % (i, ro + 3 * i, i, ro + 3 * i + 1, i, ro + 3 * i + 2))
-    A("T Rc[9] = {static_cast<T>(1), Z, Z, Z, static_cast<T>(1), Z, Z, Z, static_cast<T>(1)};")
-    A("T pc[3] = {Z, Z, Z};")
-    A("#pragma unroll")
-    A("for (int r = 0; r < 9; r++) { myR[r] = Rc[r]; TR[r] = Rc[r]; }")
-    A("#pragma unroll")
-    A("for (int r = 0; r < 3; r++) { myp[r] = pc[r]; Tp[r] = pc[r]; }")
-    junction_steps = sorted(set(len(P["branches"][b]) for b in range(P["nb"]) if P["pb"][b] >= 0))
-    root_steps = sorted(set(len(p_) - 1 for p_ in P["paths"]))
-    A("T En[9]; // E(q) of the next path joint (parent -> child coordinates, row-major): read one step ahead")
-    A("#pragma unroll")
-    A("for (int r = 0; r < 9; r++) { En[r] = s_X[GRID_X_STRIDE*pj0 + r]; }")
-    A("T *s_sp_dst = (active && pos == 0) ? s_Sp : %s; // the first lane of every branch parks the joint axes of the path; the others write to %s"
-      % ((zero[0], "the head of the result image (cleared below)") if spare_in_image else ("&s_SP[%d]" % P["sp_spare"], "a spare set of records")))
-    for i in range(D):
-        A("{ // path step %d" % i, True)
-        A("T Ei[9];")
+    chain_scan = branch_chain_scan(self)
+    if chain_scan:
+        _emit_chain_scan(self, P, H, RL, bfam, kin, use_thread_group, ptr)
+    else:
+        A("{", True)
+        ro = H + D + max(maxchild, 1)
+        A("T rj[%d][3]; // origins of the path joints' frames in their parents' coordinates: all table reads issued before the first use" % D)
+        for i in range(D - 1):
+            A("rj[%d][0] = d_L[%d]; rj[%d][1] = d_L[%d]; rj[%d][2] = d_L[%d];" % (i, ro + 3 * i, i, ro + 3 * i + 1, i, ro + 3 * i + 2))
+        A("T Rc[9] = {static_cast<T>(1), Z, Z, Z, static_cast<T>(1), Z, Z, Z, static_cast<T>(1)};")
+        A("T pc[3] = {Z, Z, Z};")
         A("#pragma unroll")
-        A("for (int r = 0; r < 9; r++) { Ei[r] = En[r]; }")
-        if i < D - 1:
-            A("#pragma unroll")
-            A("for (int r = 0; r < 9; r++) { En[r] = s_X[GRID_X_STRIDE*pj%d + r]; }" % (i + 1))
-        if 0 < i < maxLb:
-            A("#pragma unroll")
-            A("for (int r = 0; r < 9; r++) { myR[r] = (own == %d) ? Rc[r] : myR[r]; }" % i)
-            A("#pragma unroll")
-            A("for (int r = 0; r < 3; r++) { myp[r] = (own == %d) ? pc[r] : myp[r]; }" % i)
-        if bfam and 0 < i < maxLb:
-            A("pB[0] = (iB == %d) ? pc[0] : pB[0]; pB[1] = (iB == %d) ? pc[1] : pB[1]; pB[2] = (iB == %d) ? pc[2] : pB[2];" % (i, i, i))
-        if i in junction_steps:
-            A("#pragma unroll")
-            A("for (int r = 0; r < 9; r++) { TR[r] = (Lb == %d) ? Rc[r] : TR[r]; } // pose of the parent branch's frame in this branch's frame" % i)
-            A("#pragma unroll")
-            A("for (int r = 0; r < 3; r++) { Tp[r] = (Lb == %d) ? pc[r] : Tp[r]; }" % i)
-        A("{ // joint axis of path joint %d in the branch frame, parked for the walks below (zero beyond the root)" % i)
-        A("  const int pa = pc%d & 3; T w[3];" % i)
-        A("  #pragma unroll")
-        A("  for (int r = 0; r < 3; r++) { const T wr = (pa == 0) ? Rc[3*r] : ((pa == 1) ? Rc[3*r + 1] : Rc[3*r + 2]); w[r] = pv%d ? wr : Z; }" % i)
-        A("  s_sp_dst[%d] = w[0]; s_sp_dst[%d] = w[1]; s_sp_dst[%d] = w[2];" % (6 * i, 6 * i + 1, 6 * i + 2))
-        A("  s_sp_dst[%d] = pc[1]*w[2] - pc[2]*w[1]; s_sp_dst[%d] = pc[2]*w[0] - pc[0]*w[2]; s_sp_dst[%d] = pc[0]*w[1] - pc[1]*w[0]; }" % (6 * i + 3, 6 * i + 4, 6 * i + 5))
-        A("T Rn[9];")
+        A("for (int r = 0; r < 9; r++) { myR[r] = Rc[r]; TR[r] = Rc[r]; }")
         A("#pragma unroll")
-        A("for (int r = 0; r < 3; r++) {", True)
+        A("for (int r = 0; r < 3; r++) { myp[r] = pc[r]; Tp[r] = pc[r]; }")
+        junction_steps = sorted(set(len(P["branches"][b]) for b in range(P["nb"]) if P["pb"][b] >= 0))
+        root_steps = sorted(set(len(p_) - 1 for p_ in P["paths"]))
+        A("T En[9]; // E(q) of the next path joint (parent -> child coordinates, row-major): read one step ahead")
         A("#pragma unroll")
-        A("for (int c = 0; c < 3; c++) { Rn[3*r + c] = Rc[3*r]*Ei[c] + Rc[3*r + 1]*Ei[3 + c] + Rc[3*r + 2]*Ei[6 + c]; }")
+        A("for (int r = 0; r < 9; r++) { En[r] = s_X[GRID_X_STRIDE*pj0 + r]; }")
+        A("T *s_sp_dst = (active && pos == 0) ? s_Sp : %s; // the first lane of every branch parks the joint axes of the path; the others write to %s"
+          % ((zero[0], "the head of the result image (cleared below)") if spare_in_image else ("&s_SP[%d]" % P["sp_spare"], "a spare set of records")))
+        for i in range(D):
+            A("{ // path step %d" % i, True)
+            A("T Ei[9];")
+            A("#pragma unroll")
+            A("for (int r = 0; r < 9; r++) { Ei[r] = En[r]; }")
+            if i < D - 1:
+                A("#pragma unroll")
+                A("for (int r = 0; r < 9; r++) { En[r] = s_X[GRID_X_STRIDE*pj%d + r]; }" % (i + 1))
+            if 0 < i < maxLb:
+                A("#pragma unroll")
+                A("for (int r = 0; r < 9; r++) { myR[r] = (own == %d) ? Rc[r] : myR[r]; }" % i)
+                A("#pragma unroll")
+                A("for (int r = 0; r < 3; r++) { myp[r] = (own == %d) ? pc[r] : myp[r]; }" % i)
+            if bfam and 0 < i < maxLb:
+                A("pB[0] = (iB == %d) ? pc[0] : pB[0]; pB[1] = (iB == %d) ? pc[1] : pB[1]; pB[2] = (iB == %d) ? pc[2] : pB[2];" % (i, i, i))
+            if i in junction_steps:
+                A("#pragma unroll")
+                A("for (int r = 0; r < 9; r++) { TR[r] = (Lb == %d) ? Rc[r] : TR[r]; } // pose of the parent branch's frame in this branch's frame" % i)
+                A("#pragma unroll")
+                A("for (int r = 0; r < 3; r++) { Tp[r] = (Lb == %d) ? pc[r] : Tp[r]; }" % i)
+            A("{ // joint axis of path joint %d in the branch frame, parked for the walks below (zero beyond the root)" % i)
+            A("  const int pa = pc%d & 3; T w[3];" % i)
+            A("  #pragma unroll")
+            A("  for (int r = 0; r < 3; r++) { const T wr = (pa == 0) ? Rc[3*r] : ((pa == 1) ? Rc[3*r + 1] : Rc[3*r + 2]); w[r] = pv%d ? wr : Z; }" % i)
+            A("  s_sp_dst[%d] = w[0]; s_sp_dst[%d] = w[1]; s_sp_dst[%d] = w[2];" % (6 * i, 6 * i + 1, 6 * i + 2))
+            A("  s_sp_dst[%d] = pc[1]*w[2] - pc[2]*w[1]; s_sp_dst[%d] = pc[2]*w[0] - pc[0]*w[2]; s_sp_dst[%d] = pc[0]*w[1] - pc[1]*w[0]; }" % (6 * i + 3, 6 * i + 4, 6 * i + 5))
+            A("T Rn[9];")
+            A("#pragma unroll")
+            A("for (int r = 0; r < 3; r++) {", True)
+            A("#pragma unroll")
+            A("for (int c = 0; c < 3; c++) { Rn[3*r + c] = Rc[3*r]*Ei[c] + Rc[3*r + 1]*Ei[3 + c] + Rc[3*r + 2]*Ei[6 + c]; }")
+            self.gen_add_end_control_flow()
+            if i in root_steps and kin:
+                A("gvec[0] = (plen == %d) ? gravity*Rn[2] : gvec[0]; gvec[1] = (plen == %d) ? gravity*Rn[5] : gvec[1]; gvec[2] = (plen == %d) ? gravity*Rn[8] : gvec[2]; // base acceleration (0,0,g) in this branch's coordinates" % (i + 1, i + 1, i + 1))
+            if i < D - 1:
+                A("#pragma unroll")
+                A("for (int r = 0; r < 3; r++) { pc[r] -= Rn[3*r]*rj[%d][0] + Rn[3*r + 1]*rj[%d][1] + Rn[3*r + 2]*rj[%d][2]; }" % (i, i, i))
+                A("#pragma unroll")
+                A("for (int r = 0; r < 9; r++) { Rc[r] = Rn[r]; }")
+                A("GRID_SCHED_FENCE();")
+            self.gen_add_end_control_flow()
         self.gen_add_end_control_flow()
-        if i in root_steps and kin:
-            A("gvec[0] = (plen == %d) ? gravity*Rn[2] : gvec[0]; gvec[1] = (plen == %d) ? gravity*Rn[5] : gvec[1]; gvec[2] = (plen == %d) ? gravity*Rn[8] : gvec[2]; // base acceleration (0,0,g) in this branch's coordinates" % (i + 1, i + 1, i + 1))
-        if i < D - 1:
-            A("#pragma unroll")
-            A("for (int r = 0; r < 3; r++) { pc[r] -= Rn[3*r]*rj[%d][0] + Rn[3*r + 1]*rj[%d][1] + Rn[3*r + 2]*rj[%d][2]; }" % (i, i, i))
-            A("#pragma unroll")
-            A("for (int r = 0; r < 9; r++) { Rc[r] = Rn[r]; }")
-            A("GRID_SCHED_FENCE();")
-        self.gen_add_end_control_flow()
-    self.gen_add_end_control_flow()
     _probe(self, "chain", "myR:9", "myp:3", "TR:9", "Tp:3", "gvec:3")
     self.gen_add_sync(use_thread_group)
-    if spare_in_image:
+    if spare_in_image and not chain_scan:
         A("// (the head of the result image took the spare path records: clear it now)")
         A("if (lane < %d) {" % lanes_head, True)
         A("#pragma unroll")
