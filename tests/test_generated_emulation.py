@@ -61,10 +61,10 @@ def test_emulated_one_column_per_lane_variant(name, golden):
     assert per_solve_err(dc, np.stack([g["dc_du"][k].T.reshape(-1) for k in range(N)])) <= TOL
 
 
-@pytest.mark.parametrize("name,tuning", [("iiwa14", {"gradient_walk": "lds"}), ("hyq", {"gradient_walk": "lds"}), ("atlas", {"gradient_walk": "lds"}),
+@pytest.mark.parametrize("name,tuning", [("iiwa14", {"gradient_walk": "lds"}), ("hyq", {"gradient_walk": "lds"}),
                                       ("iiwa14", {"reuse_rnea": True}), ("iiwa14", {"fuse_fd": False}),
                                       ("iiwa14", {"gradient_walk": "registers"}), ("iiwa14", {"tip_chain": "lds"}), ("arm6", {"gradient_walk": "registers"}),
-                                      ("iiwa14", {"gradient_walk": "branch"}), ("hyq", {"gradient_walk": "branch"}), ("chain12", {"gradient_walk": "branch"}),
+                                      ("iiwa14", {"gradient_walk": "branch"}), ("hyq", {"gradient_walk": "branch"}),
                                       ("atlas", {"gradient_walk": "registers"}), ("tree12", {"stream_out": True}), ("tree12", {"factor_split": "branch"}), ("atlas", {"factor_split": "component"}),
                                       ("hyq", {"gradient_walk": "branch", "factor_split": "branch"}), ("atlas", {"branch_chain": "scan"}), ("tree12", {"branch_chain": "scan"}),
                                       ("chain12", {"branch_chain": "walk"})])
@@ -362,7 +362,7 @@ def _random_tree_description(seed, n):
     return dict(name="rnd%d" % seed, base_link="base", joints=joints)
 
 
-@pytest.mark.parametrize("seed,n,tuning", [(16, 8, {}), (13, 7, {}), (1, 9, {}), (2, 14, {}), (3, 20, {}), (4, 27, {}),  # (8-lane groups with two tree levels / two components, ..., 32-lane groups)
+@pytest.mark.parametrize("seed,n,tuning", [(16, 8, {}), (13, 7, {}), (1, 9, {}), (4, 27, {}),  # (8-lane groups with two tree levels / two components, ..., 32-lane groups)
                                            (58, 20, {"factor_split": "branch", "stream_out": True}), (61, 11, {"factor_split": "branch"})])  # (three / four tree levels)
 def test_emulated_random_trees_on_the_branch_frame_path(seed, n, tuning):
     """Generator robustness: random tree topologies (nesting depth, component shapes, lane packing all vary) through the unchanged
