@@ -83,5 +83,5 @@ def test_emulated_second_order_layout_from_first_order_kernels():
         full = staticmethod(lambda shape, v: np.full(shape, v, dtype=np.float32))
         host = staticmethod(lambda a: a)
 
-    report = check_second_order_layout(lib, Dev, B=2)
+    report = check_second_order_layout(lib, Dev, B=1)
     assert max(report.values()) < 5e-2
