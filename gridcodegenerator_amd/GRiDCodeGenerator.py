@@ -428,7 +428,7 @@ class GRiDCodeGenerator:
             probe = GRiDCodeGenerator(self.robot, COLS_PER_LANE=self._ctor["COLS_PER_LANE"], tuning=dict(self._ctor["tuning"], min_lanes=2 * self.lanes_per_solve, so_lanes="off"))
             self._so_wide_cache = 2 * self.lanes_per_solve if probe.gen_idsva_so_mode() == self.gen_idsva_so_mode() else None
             return self._so_wide_cache
-        # measured (gpurun_out/r3e, r3g): 7-DoF arm 8 -> 16 lanes idsva_so 289 -> 195 us per 65 536 solves (32 lanes: 298); quadruped 16 -> 32 lanes
+        # measured (profiles/ab/r3e_*, r3g_*): 7-DoF arm 8 -> 16 lanes idsva_so 289 -> 195 us per 65 536 solves (32 lanes: 298); quadruped 16 -> 32 lanes
         # 414 -> 275 us per 16 384, 12-DoF tree 578 -> 431 (their 28 KB records leave ONE wave per CU at 4 solves per wave)
         if want not in (16, 32) or want <= self.lanes_per_solve:
             raise ValueError("tuning['so_lanes'] must be auto, off, or 16 / 32 and wider than the robot's lane groups")
