@@ -139,9 +139,13 @@ def gen_fdsva_so_device(self, use_thread_group=False):
     self.gen_add_code_line("void fdsva_so_device(T *df2, T *s_df_du, T *s_idsva_so, const T *s_q, const T *s_qd, const T *s_u, T *s_work, const robotModel<T> *d_robotModel, const T gravity, const int lane, const bool active) {", True)
     self.gen_add_code_line("T *s_qdd = &s_work[GRID_OFF_QDD]; T *s_Minv = &s_work[GRID_OFF_MINV];")
     self.gen_add_code_line("// (the gradient comes first: it uses the workspace freely - the M^-1 slot as scratch, on branched robots its own layout - so qdd and M^-1 are produced after it)")
-    self.gen_add_code_line("forward_dynamics_gradient_device<T>(s_df_du, s_q, s_qd, s_u, s_work, d_robotModel, gravity, lane);")
-    self.gen_add_code_line("forward_dynamics_device<T>(s_qdd, s_q, s_qd, s_u, s_work, d_robotModel, gravity, lane);")
-    self.gen_add_code_line("direct_minv_device<T>(s_Minv, s_q, s_work, d_robotModel, lane);")
+    if self.tip_frame and not getattr(self, "branch_frame", False):
+        self.gen_add_code_line("// (robots whose gradient runs the tip-frame inner: it leaves qdd and M^-1 behind - one pass instead of three)")
+        self.gen_add_code_line("forward_dynamics_gradient_device<T>(s_df_du, s_q, s_qd, s_u, s_work, d_robotModel, gravity, lane, s_qdd, s_Minv);")
+    else:
+        self.gen_add_code_line("forward_dynamics_gradient_device<T>(s_df_du, s_q, s_qd, s_u, s_work, d_robotModel, gravity, lane);")
+        self.gen_add_code_line("forward_dynamics_device<T>(s_qdd, s_q, s_qd, s_u, s_work, d_robotModel, gravity, lane);")
+        self.gen_add_code_line("direct_minv_device<T>(s_Minv, s_q, s_work, d_robotModel, lane);")
     self.gen_add_code_line("idsva_so_device<T>(s_idsva_so, s_q, s_qd, s_qdd, &s_work[GRID_OFF_X], d_robotModel, gravity, lane, %s);" % ("active" if self.gen_idsva_so_direct() else "true"))
     self.gen_add_sync(use_thread_group)
     self.gen_add_code_line("fdsva_so_inner<T>(df2, s_idsva_so, s_Minv, s_df_du, lane, active);")

@@ -89,7 +89,10 @@ def gen_forward_dynamics_gradient_device(self, use_thread_group=False, use_qdd_M
     else:
         func_def += "const T *s_u, "
         func_params.insert(3, "s_u is the vector of input torques")
-    func_def += "T *s_work, const robotModel<T> *d_robotModel, const T gravity, const int lane) {"
+    fused_out = self.tip_frame and not getattr(self, "branch_frame", False) and not use_qdd_Minv_input  # the tip-frame inner can leave qdd and M^-1 behind (what fdsva_so needs besides the gradient)
+    func_def += "T *s_work, const robotModel<T> *d_robotModel, const T gravity, const int lane" + (", T *s_qdd_out = nullptr, T *s_Minv_out = nullptr" if fused_out else "") + ") {"
+    if fused_out:
+        func_params.append("s_qdd_out, s_Minv_out (optional): where to leave qdd = FD(q, qd, u) and the dense M^-1 (leading dimension GRID_MINV_LD; may be &s_work[GRID_OFF_MINV])")
     self.gen_add_func_doc("Computes the gradient of forward dynamics (lane-group cooperative, for use inside other kernels)",
                           ["Uses the fd/du = -Minv*id/du trick as described in Carpentier and Mansard 'Analytical Derivatives of Rigid Body Dynamics Algorithms'",
                            "all lanes of the solve's lane group must call it; results are visible to the group after grid_wave_sync()"], func_params, None)

@@ -547,7 +547,8 @@ def gen_forward_dynamics_gradient_inner_tip(self, use_thread_group=False, use_qd
     else:
         params += ["s_u is the vector of joint input torques in LDS", "s_X is this solve's compact X(q) storage (only the rotation blocks are read)",
                    "s_G is LDS scratch for the per-joint hand-off records (16 values per joint)", "s_M is LDS scratch for the joint-space inertia matrix (leading dimension GRID_MINV_LD)"]
-        sig = "T *s_df_du, const T *s_qd, const T *s_u, const T *s_X, T *s_G, T *s_M, const robotModel<T> *d_robotModel, const T gravity, const int lane"
+        params += ["s_qdd_out, s_Minv_out (optional, after lane): where to leave qdd = FD(q, qd, u) and the dense M^-1 (leading dimension GRID_MINV_LD; may be s_M) - what fdsva_so needs besides the gradient"]
+        sig = "T *s_df_du, const T *s_qd, const T *s_u, const T *s_X, T *s_G, T *s_M, const robotModel<T> *d_robotModel, const T gravity, const int lane, T *s_qdd_out = nullptr, T *s_Minv_out = nullptr"
     params += ["d_robotModel is the pointer to the initialized model specific helpers on the GPU", "gravity is the gravity constant",
                "lane is the caller's lane index inside the solve's lane group"]
     self.gen_add_func_doc("Computes the gradient of forward dynamics in the tip frame", notes, params, None)
@@ -722,6 +723,23 @@ def gen_forward_dynamics_gradient_inner_tip(self, use_thread_group=False, use_qd
         _own_rows(self, "s_df_du[lane*" + str(n) + " + %d]", "-dq[%d]")
         _own_rows(self, "s_df_du[(" + str(n) + " + lane)*" + str(n) + " + %d]", "-dqd[%d]")
     self.gen_add_end_control_flow()
+    if not use_qdd_Minv_input:
+        ld = self.minv_ld
+        self.gen_add_code_line("if (s_qdd_out != nullptr && lane < %d) { s_qdd_out[lane] = qdd; }" % n)
+        self.gen_add_code_line("if (s_Minv_out != nullptr) { // row (= column) `lane` of M^-1 from the register factors: one more solve, of the unit vector of this lane's joint", True)
+        self.gen_add_code_line("T e[%d];" % L)
+        self.gen_add_code_line("#pragma unroll")
+        self.gen_add_code_line("for (int k = 0; k < %d; k++) { e[k] = (k == pos) ? static_cast<T>(1) : static_cast<T>(0); }" % L)
+        _emit_ldl_solve(self, "e")
+        self.gen_add_sync(use_thread_group)  # (s_Minv_out may be the storage M was read from: every lane has read it by now)
+        self.gen_add_code_line("if (lane < %d) {" % n, True)
+        if self.tip_nseg > 1:
+            self.gen_add_code_line("#pragma unroll")
+            self.gen_add_code_line("for (int k = 0; k < %d; k++) { s_Minv_out[lane*%d + k] = static_cast<T>(0); } // (block diagonal over the chains)" % (n, ld))
+        self.gen_add_code_line("#pragma unroll")
+        self.gen_add_code_line("for (int k = 0; k < %d; k++) { s_Minv_out[lane*%d + base + k] = e[k]; }" % (L, ld))
+        self.gen_add_end_control_flow()
+        self.gen_add_end_control_flow()
     if ts_mode:
         self.gen_add_sync(use_thread_group)
         TS(6)
@@ -736,7 +754,8 @@ def gen_forward_dynamics_gradient_inner_tip_function_call(self, use_thread_group
     if use_qdd_Minv_input:
         self.gen_add_code_line("forward_dynamics_gradient_inner_tip_qdd_minv<T>(%s, s_qd, s_qdd, s_Minv, s_X, d_robotModel, gravity, lane);" % s_df_du_name)
     else:
-        self.gen_add_code_line("forward_dynamics_gradient_inner_tip<T>(%s, s_qd, s_u, s_X, s_U, s_Minv, d_robotModel, gravity, lane); // hand-off records in the U|T scratch, M in the M^-1 slot" % s_df_du_name)
+        fused = "s_qdd_out, s_Minv_out" if not getattr(self, "branch_frame", False) else "nullptr, nullptr"  # (the device function has these parameters where its inner is this one)
+        self.gen_add_code_line("forward_dynamics_gradient_inner_tip<T>(%s, s_qd, s_u, s_X, s_U, s_Minv, d_robotModel, gravity, lane, %s); // hand-off records in the U|T scratch, M in the M^-1 slot" % (s_df_du_name, fused))
 
 
 def _emit_force_only(self, with_qdd):

@@ -295,7 +295,7 @@ def test_emulated_second_order_is_refused_where_it_is_not_emitted(name, n, libs)
         lib.fdsva_so_device(np.zeros((1, 3 * n), np.float32), 1, np.zeros((1, 4), np.float32))
 
 
-@pytest.mark.parametrize("name", ["iiwa14", "arm6", "hyq", "tree12", "atlas"])
+@pytest.mark.parametrize("name", ["iiwa14", "arm6", "hyq", "tree12", "atlas", "chain12"])
 def test_emulated_fdsva_so(name, libs, golden):
     """Second half of SURVEY.md section 8(f) rank 3: second-order derivatives of forward dynamics, against the NumPy restatements of the reference's
     idsva_so + fdsva_so emitters fed by the pinned first-order oracle (parity unpinned, see oracle/fdsva_so_oracle.py)."""
