@@ -142,6 +142,11 @@ def gen_fdsva_so_device(self, use_thread_group=False):
     if self.tip_frame and not getattr(self, "branch_frame", False):
         self.gen_add_code_line("// (robots whose gradient runs the tip-frame inner: it leaves qdd and M^-1 behind - one pass instead of three)")
         self.gen_add_code_line("forward_dynamics_gradient_device<T>(s_df_du, s_q, s_qd, s_u, s_work, d_robotModel, gravity, lane, s_qdd, s_Minv);")
+    elif getattr(self, "branch_frame", False):
+        self.gen_add_code_line("// (branch-frame robots: the gradient's inner leaves qdd in its slice, FD_DU_OFF_QDD - inside the input block, which nothing below overwrites)")
+        self.gen_add_code_line("forward_dynamics_gradient_device<T>(s_df_du, s_q, s_qd, s_u, s_work, d_robotModel, gravity, lane);")
+        self.gen_add_code_line("s_qdd = &s_work[FD_DU_OFF_QDD];")
+        self.gen_add_code_line("direct_minv_device<T>(s_Minv, s_q, s_work, d_robotModel, lane);")
     else:
         self.gen_add_code_line("forward_dynamics_gradient_device<T>(s_df_du, s_q, s_qd, s_u, s_work, d_robotModel, gravity, lane);")
         self.gen_add_code_line("forward_dynamics_device<T>(s_qdd, s_q, s_qd, s_u, s_work, d_robotModel, gravity, lane);")
