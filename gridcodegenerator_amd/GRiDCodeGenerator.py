@@ -25,6 +25,10 @@ TUNING_DEFAULTS = {
     "min_waves": 0,             # second __launch_bounds__ argument (minimum waves per SIMD); 0 = compiler's choice
     "so_unroll": None,          # inner-loop unrolling of idsva_so (None = full; subtree mapping only)
     "so_mapping": "balanced",   # balanced | subtree: work distribution of the idsva_so main loops (algorithms/_idsva_so.py: gen_idsva_so_items)
+    "so_loops": "dots",         # dots | mxm: loop bodies of the balanced idsva_so main loops - every cross product folded into per-item vectors, a step is dot products
+                                # only (algorithms/_idsva_so.py: _SO_FOLD), or the round-2 bodies with motion cross products per step
+    "so_stage": "auto",         # auto | compact | dense: LDS staging of the idsva_so record - compact = every value once (symmetric entries, no structural zeros), expanded
+                                # through the table grid_so_expand on the way out (auto: serial chains whose record is staged in LDS)
     "min_lanes": 8,             # smallest lane group (8 | 16 | 32 | 64): wider groups than the joint count needs leave lanes idle in the first-order kernels but
                                 # give the item loops of the second-order kernels more lanes per solve (and fewer solves' staging per wave)
     "so_lanes": "auto",         # auto | off | 16 | 32: lane-group width of the second-order KERNELS.  Robots with 8- or 16-lane groups get a second instance of the
@@ -81,6 +85,8 @@ def resolve_tuning(tuning=None, COLS_PER_LANE=None):
         raise ValueError("tuning['cols_per_lane'] must be 1 or 2")
     if t["tip_chain"] not in ("select", "lds"):
         raise ValueError("tuning['tip_chain'] must be select or lds")
+    if t["so_loops"] not in ("dots", "mxm"):
+        raise ValueError("tuning['so_loops'] must be dots or mxm")
     return t
 
 
@@ -88,7 +94,7 @@ class GRiDCodeGenerator:
     # emission primitives, device math, model constants (free functions taking self, like the reference's layout)
     from .helpers import gen_add_code_line, gen_add_code_lines, gen_add_end_control_flow, gen_add_end_function, \
         gen_add_func_doc, gen_add_serial_ops, gen_add_parallel_loop, gen_add_sync, gen_var_in_list, gen_var_not_in_list, gen_add_multi_threaded_select, \
-        gen_lane_mask_test, gen_kernel_prologue, gen_kernel_load_inputs, gen_kernel_save_result, gen_kernel_load_inputs_single_timing, gen_kernel_save_result_single_timing, \
+        gen_lane_mask_test, gen_kernel_prologue, gen_kernel_load_inputs, gen_kernel_save_result, gen_kernel_save_result_expanded, gen_kernel_load_inputs_single_timing, gen_kernel_save_result_single_timing, \
         gen_static_array_ind_2d, gen_static_array_ind_3d, gen_add_debug_print_code_line, gen_add_debug_print_code_lines, \
         gen_spatial_algebra_helpers, gen_mx_func_call_for_cpp, \
         gen_lds_layout, gen_model_constant_table, gen_get_XI_size, gen_topology_helpers_size, gen_init_XImats, gen_init_topology_helpers, gen_init_robotModel, \
@@ -104,7 +110,7 @@ class GRiDCodeGenerator:
         gen_forward_dynamics_inner_function_call, gen_forward_dynamics_inner, gen_forward_dynamics_device, gen_forward_dynamics_kernel, \
         gen_forward_dynamics_host, gen_forward_dynamics, \
         gen_aba_inner_temp_mem_size, gen_aba_inner_function_call, gen_aba_inner, gen_aba_device, gen_aba_kernel, gen_aba_host, gen_aba, \
-        gen_idsva_so_available, gen_idsva_so_mode, gen_idsva_so_direct, gen_idsva_so_rec, gen_idsva_so_tree_tables, gen_idsva_so_items, gen_idsva_so_items_table, gen_idsva_so_lds_layout, gen_idsva_so_inner_temp_mem_size, gen_idsva_so_inner_function_call, gen_idsva_so_inner, gen_idsva_so_device, gen_idsva_so_kernel, gen_idsva_so_host, gen_idsva_so, \
+        gen_idsva_so_available, gen_idsva_so_mode, gen_idsva_so_direct, gen_idsva_so_compact, gen_idsva_so_compact_layout, gen_idsva_so_rec, gen_idsva_so_tree_tables, gen_idsva_so_items, gen_idsva_so_items_table, gen_idsva_so_lds_layout, gen_idsva_so_inner_temp_mem_size, gen_idsva_so_inner_function_call, gen_idsva_so_inner, gen_idsva_so_device, gen_idsva_so_kernel, gen_idsva_so_host, gen_idsva_so, \
         gen_fdsva_so_inner_temp_mem_size, gen_fdsva_so_stage_size, gen_fdsva_so_inner, gen_fdsva_so_device, gen_fdsva_so_kernel, gen_fdsva_so_host, gen_fdsva_so, \
         gen_inverse_dynamics_gradient_inner_temp_mem_size, gen_inverse_dynamics_gradient_kernel_max_temp_mem_size, \
         gen_inverse_dynamics_gradient_inner_function_call, gen_inverse_dynamics_gradient_inner, gen_dc_du_to_lds, gen_gradient_slots, gen_gradient_outputs_decl, \
@@ -298,6 +304,7 @@ class GRiDCodeGenerator:
             sl_, scr_, stg_, thr_ = self.gen_idsva_so_lds_layout()
             if scr_ > lds["MINV"] - lds["X"]:
                 raise ValueError("idsva_so scratch (%d) does not fit between X(q) and M^-1 of the general slice (fdsva_so_device runs it there)" % scr_)
+            self.gen_add_code_line("#define GRID_SO_COMPACT %d // 1: the kernels stage the idsva_so record of a solve in compact form (every value once) and expand it through grid_so_expand" % (1 if self.gen_idsva_so_compact() else 0))
             self.gen_add_code_lines(["#define GRID_SO_DIRECT %d // 1: the 4 n^3 record of one solve does not fit LDS - idsva_so writes it entry by entry to global memory, fdsva_so_kernel takes a d_idsva_so workspace" % (1 if self.gen_idsva_so_direct() else 0),
                                      "// init_gridData sizes the second-order buffers (d_idsva_so, d_df2 and their pinned host twins: 4 n^3 values per solve) for at most this many solves",
                                      "// (1 GiB per buffer); the second-order host wrappers reject longer batches with hipErrorInvalidValue",
@@ -315,8 +322,8 @@ class GRiDCodeGenerator:
             per = (lds["TOTAL"] + st_) * 4
             best_g, best_res = 1, 0
             for g_ in range(max(1, -(-24 // G)), max(1, 64 // G) + 1):  # (at least 24 lanes of a wave in use)
-                res = (155 * 1024 // (g_ * per)) * g_
-                if res > best_res:
+                res = min(155 * 1024 // (g_ * per), 8) * g_  # (blocks of at most one wave; the kernel holds > 168 VGPRs: at most 8 waves per CU)
+                if res > best_res:  # (ties go to the smaller block: more waves for the same number of resident solves)
                     best_g, best_res = g_, res
             fd_so_threads = best_g * G
             self.gen_add_code_lines(["const int FDSVA_SO_SUGGESTED_THREADS = %d; // fdsva_so keeps the 4 n^3 idsva_so tensors of every solve in LDS: fewer solves per block" % fd_so_threads,

@@ -55,6 +55,46 @@ for (int k = 0; k < @N@; k++) {
 """
 
 
+# the same contraction reading the idsva_so tensors from the COMPACT staging record (algorithms/_idsva_so.py: gen_idsva_so_compact_layout): symmetric entries
+# through their canonical index, dM_dq[L][a][p] = d M_Lp / d q_a from mqc[tri(max(L, p)) + min(L, p)][a], structurally zero for a <= min(L, p)
+_COMPACT = """
+const T *q2c = s_idsva_so + @Q2@, *qd2c = s_idsva_so + @QD2@, *tvq = s_idsva_so + @VQ@, *mqc = s_idsva_so + @MQ@;
+@SPLIT@
+T fq_j[@N@], fv_j[@N@], mi_j[@N@]; // column j of df/dq and of df/dqd, row j of M^-1
+#pragma unroll
+for (int p = 0; p < @N@; p++) { fq_j[p] = s_df_du[j*@N@ + p]; fv_j[p] = s_df_du[(@N@ + j)*@N@ + p]; mi_j[p] = s_Minv[j*@LD@ + p]; }
+#pragma unroll 1
+for (int k = @K0@; k < @N@; k += @KSTEP@) {
+    T fq_k[@N@];
+    #pragma unroll
+    for (int p = 0; p < @N@; p++) { fq_k[p] = s_df_du[k*@N@ + p]; }
+    const int hi = (k > j) ? k : j, lo = (k > j) ? j : k, kj = (hi*(hi + 1) >> 1) + lo; // (k, j) in the symmetric tensors
+    T rq[@N@], rc[@N@], rv[@N@], rt[@N@]; // inner_dq, inner_cross, d2tau_dvdv, inner_tau at (L, k, j), L = 0..n-1
+    #pragma unroll
+    for (int L = 0; L < @N@; L++) {
+        T aq = q2c[L*@TRI@ + kj], ac = tvq[(L*@N@ + k)*@N@ + j], at = static_cast<T>(0);
+        #pragma unroll
+        for (int p = 0; p < @N@; p++) {
+            const int plo = (L < p) ? L : p, phi = (L < p) ? p : L, base = ((phi*(phi + 1) >> 1) + plo)*@N@; // (compile-time after unrolling)
+            const T mk = (k > plo) ? mqc[base + k] : static_cast<T>(0), mj = (j > plo) ? mqc[base + j] : static_cast<T>(0);
+            aq += mj*fq_k[p] + mk*fq_j[p]; ac += mk*fv_j[p]; at += mk*mi_j[p];
+        }
+        rq[L] = aq; rc[L] = ac; rt[L] = at; rv[L] = qd2c[L*@TRI@ + kj];
+    }
+    #pragma unroll
+    for (int i = 0; i < @N@; i++) {
+        T oq = static_cast<T>(0), oc = static_cast<T>(0), ov = static_cast<T>(0), ot = static_cast<T>(0);
+        #pragma unroll
+        for (int L = 0; L < @N@; L++) { const T mi = s_Minv[L*@LD@ + i]; oq += mi*rq[L]; oc += mi*rc[L]; ov += mi*rv[L]; ot += mi*rt[L]; }
+        if (own) {
+            const int e = (i*@N@ + k)*@N@ + j;
+            df2[e] = -oq; df2[@N3@ + e] = -ov; df2[2*@N3@ + e] = -oc; df2[3*@N3@ + e] = -ot;
+        }
+    }
+}
+"""
+
+
 def gen_fdsva_so_inner_temp_mem_size(self):
     return 0
 
@@ -63,7 +103,7 @@ def gen_fdsva_so_stage_size(self):
     """Per-solve staging behind the block's slices: df/du (2 n^2, padded) then the idsva_so tensors (4 n^3; in the direct form of large robots they
     stay in a global workspace, gen_idsva_so_direct)."""
     n = self.model.n
-    return (2 * n * n + 3) // 4 * 4 + (0 if self.gen_idsva_so_direct() else 4 * n * n * n)
+    return (2 * n * n + 3) // 4 * 4 + (0 if self.gen_idsva_so_direct() else (self.gen_idsva_so_compact_layout()["SIZE"] if self.gen_idsva_so_compact() else 4 * n * n * n))
 
 
 def gen_fdsva_so_inner(self, use_thread_group=False):
@@ -73,14 +113,15 @@ def gen_fdsva_so_inner(self, use_thread_group=False):
     self.gen_add_func_doc("Second Order of Forward Dynamics with Spatial Vector Algebra: the contraction of the idsva_so tensors with M^-1 and df/du",
                           ["lane j produces the entries (., k, j) of the four output tensors and stores each exactly once; all lanes of the lane group must call it"],
                           ["df2 is the output record of this solve: 4*NUM_JOINTS^3 values [d2a_dqdq | d2a_dvdv | d2a_dvdq | d2a_dtdq] (global or LDS memory)",
-                           "s_idsva_so are the second derivative tensors of inverse dynamics at qdd = FD(q, qd, u), in LDS (large robots: global workspace)",
+                           "s_idsva_so are the second derivative tensors of inverse dynamics at qdd = FD(q, qd, u), in LDS (large robots: global workspace)" + ("; COMPACT staging record (idsva_so_inner_compact)" if self.gen_idsva_so_compact() else ""),
                            "s_Minv is the dense symmetric inverse mass matrix in LDS (leading dimension GRID_MINV_LD)",
                            "s_df_du is the gradient of the forward dynamics in LDS ([col*n + row], col in [0, 2n))",
                            "lane is the caller's lane index inside the solve's lane group", "active is false for lane groups without a solve"], None)
     self.gen_add_code_line("template <typename T>")
     self.gen_add_code_line("__device__ __forceinline__")
     self.gen_add_code_line("void fdsva_so_inner(T *df2, const T *s_idsva_so, const T *s_Minv, const T *s_df_du, const int lane, const bool active) {", True)
-    lines = (_ROLLED if n > 12 else """
+    compact = self.gen_idsva_so_compact()
+    lines = (_COMPACT if compact else _ROLLED if n > 12 else """
 const T *tqq = s_idsva_so, *tvv = s_idsva_so + @N3@, *tvq = s_idsva_so + 2*@N3@, *dM = s_idsva_so + 3*@N3@;
 @SPLIT@
 T fq_j[@N@], fv_j[@N@], mi_j[@N@]; // column j of df/dq and of df/dqd, row j of M^-1
@@ -113,10 +154,14 @@ for (int k = @K0@; k < @N@; k += @KSTEP@) {
 }
 """)
     G = self.lanes_per_solve
-    if n <= 12 and G // 2 >= n:  # lane groups at least twice as wide as the robot has joints (the `wide` instances): the two halves of the group take alternate k
+    if (n <= 12 or compact) and G // 2 >= n:  # lane groups at least twice as wide as the robot has joints (the `wide` instances): the two halves of the group take alternate k
         lines = lines.replace("@SPLIT@", "const int jl = lane %% %d, kh = lane / %d; // joint and k parity of this lane\nconst int j = (jl < @N@) ? jl : 0;\nconst bool own = active && (jl < @N@);" % (G // 2, G // 2)).replace("@K0@", "kh").replace("@KSTEP@", "2")
     else:
         lines = lines.replace("@SPLIT@", "const int j = (lane < @N@) ? lane : 0;\nconst bool own = active && (lane < @N@);").replace("@K0@", "0").replace("@KSTEP@", "1")
+    if compact:
+        L_ = self.gen_idsva_so_compact_layout()
+        for k_ in ("Q2", "QD2", "VQ", "MQ", "TRI"):
+            lines = lines.replace("@%s@" % k_, str(L_[k_]))
     lines = lines.replace("@N3@", str(n3)).replace("@N@", str(n)).replace("@LD@", str(ld))
     for line in lines.strip("\n").split("\n"):
         self.gen_add_code_line(line)
@@ -151,7 +196,7 @@ def gen_fdsva_so_device(self, use_thread_group=False):
         self.gen_add_code_line("forward_dynamics_gradient_device<T>(s_df_du, s_q, s_qd, s_u, s_work, d_robotModel, gravity, lane);")
         self.gen_add_code_line("forward_dynamics_device<T>(s_qdd, s_q, s_qd, s_u, s_work, d_robotModel, gravity, lane);")
         self.gen_add_code_line("direct_minv_device<T>(s_Minv, s_q, s_work, d_robotModel, lane);")
-    self.gen_add_code_line("idsva_so_device<T>(s_idsva_so, s_q, s_qd, s_qdd, &s_work[GRID_OFF_X], d_robotModel, gravity, lane, %s);" % ("active" if self.gen_idsva_so_direct() else "true"))
+    self.gen_add_code_line("idsva_so_device%s<T>(s_idsva_so, s_q, s_qd, s_qdd, &s_work[GRID_OFF_X], d_robotModel, gravity, lane, %s);" % ("_compact" if self.gen_idsva_so_compact() else "", "active" if self.gen_idsva_so_direct() else "true"))
     self.gen_add_sync(use_thread_group)
     self.gen_add_code_line("fdsva_so_inner<T>(df2, s_idsva_so, s_Minv, s_df_du, lane, active);")
     self.gen_add_end_function()
@@ -180,7 +225,7 @@ def gen_fdsva_so_kernel(self, use_thread_group=False, single_call_timing=False):
     self.gen_add_code_line(func_def, True)
     self.gen_kernel_prologue("GRID_LDS_PER_SOLVE", "FDSVA_SO_MAX_SOLVES_PER_BLOCK")
     self.gen_add_code_lines(["T *s_q_qd_u = &s_mem[GRID_OFF_IN]; T *s_q = s_q_qd_u; T *s_qd = &s_q_qd_u[%d]; T *s_u = &s_q_qd_u[%d];" % (n, 2 * n),
-                             "T *s_df_du = &s_out_all[grp*%d];" % stage + ("" if direct else " T *s_idsva_so = s_df_du + %d;" % (stage - 4 * n3))])
+                             "T *s_df_du = &s_out_all[grp*%d];" % stage + ("" if direct else " T *s_idsva_so = s_df_du + %d;" % ((2 * n * n + 3) // 4 * 4))])
     if single_call_timing:
         self.gen_add_code_line("const int k = 0; const int kc = 0; const bool valid = (blockIdx.x + blockIdx.y == 0) && (grp == 0); const int lane = lane_id;")
         self.gen_add_code_line("if (!valid) {return;}")

@@ -75,11 +75,11 @@ def gen_idsva_so_lds_layout(self):
     sl = pad4(3 * n) + scratch
     if (sl // 4) % 2 == 0:
         sl += 4
-    stage = 0 if self.gen_idsva_so_direct() else 4 * n * n * n
+    stage = 0 if self.gen_idsva_so_direct() else (self.gen_idsva_so_compact_layout()["SIZE"] if self.gen_idsva_so_compact() else 4 * n * n * n)
     # block size: full waves unless fewer lane groups per block let at least a quarter more solves be resident on a CU (quadruped, 32-lane groups, 16 384
     # solves: one solve per block 231 us, two 274; 6-DoF arm, 16-lane groups, 65 536 solves: four per block 135 us, three - 8 % more resident - 180)
     per = (sl + stage) * 4
-    resident = lambda g_: min((155 * 1024 // (g_ * per)) * g_, 16 * min(g_, max(1, 64 // G)))  # (LDS capacity, and at most 16 waves per CU)
+    resident = lambda g_: min(155 * 1024 // (g_ * per), 8) * g_  # (LDS capacity, and at most 8 waves per CU: the kernels hold more than 168 VGPRs)
     best_g = max(1, 64 // G)
     for g_ in range(max(1, 32 // G), best_g):
         if 4 * resident(g_) >= 5 * resident(best_g):
@@ -113,14 +113,15 @@ def gen_idsva_so_tree_tables(self):
     return fl, it, K, maxc
 
 
-def gen_idsva_so_inner_function_call(self, use_thread_group=False, use_qdd_input=False, updated_var_names=None):
-    self.gen_add_code_line("idsva_so_inner<T>(so, s_qd, s_qdd, s_X, d_robotModel, gravity, lane, active);")
+def gen_idsva_so_inner_function_call(self, use_thread_group=False, use_qdd_input=False, updated_var_names=None, compact=False):
+    self.gen_add_code_line("idsva_so_inner" + ("_compact" if compact else "") + "<T>(so, s_qd, s_qdd, s_X, d_robotModel, gravity, lane, active);")
 
 
-def gen_idsva_so_inner(self, use_thread_group=False, use_qdd_input=False):
+def gen_idsva_so_inner(self, use_thread_group=False, use_qdd_input=False, compact=False):
     if self.gen_idsva_so_mode() == "tree":
+        assert not compact
         return gen_idsva_so_inner_tree(self, use_thread_group)
-    return gen_idsva_so_inner_chain(self, use_thread_group)
+    return gen_idsva_so_inner_chain(self, use_thread_group, compact)
 
 
 def gen_idsva_so_items(self):
@@ -134,14 +135,19 @@ def gen_idsva_so_items(self):
     m_ = self.model
     n, G = m_.n, self.lanes_per_solve
     depth = m_.depth
+    dots = self.tuning["so_loops"] == "dots"  # (that form handles the step l = m of the ancestor loop before the loop: one trip fewer)
     items = []
     for c in range(n):
         for a in sorted(m_.ancestors[c]) + [c]:
-            items.append((c, a, depth[c] - depth[a] + 1, depth[a] + 1))
+            items.append((c, a, depth[c] - depth[a] + 1, depth[a] + (0 if dots else 1)))
     slots = (len(items) + G - 1) // G
     best = None
+    cI, cA, cB = (800, 75, 95) if dots else (450, 130, 200)  # instructions per item / path step / ancestor step (static counts of the emitted bodies)
     # all lanes of a slot run the path loop and the ancestor loop to the slot's longest trip counts: try a few orderings, keep the cheapest packing
-    for key in (lambda it: (-(it[2] + it[3]), -it[2]), lambda it: (-it[2], -it[3]), lambda it: (-it[3], -it[2]), lambda it: (-(it[2] + it[3]), -it[3])):
+    # (the `it[2] - it[3]` orders put the items with long paths and few ancestors together and those with many ancestors together:
+    # 7-joint chain, 16 lanes: 10 + 9 steps instead of 12 + 10)
+    for key in (lambda it: (-(it[2] + it[3]), -it[2]), lambda it: (-it[2], -it[3]), lambda it: (-it[3], -it[2]), lambda it: (-(it[2] + it[3]), -it[3]),
+                lambda it: (-(it[2] - it[3]), -it[2]), lambda it: (-(it[2] - it[3]), -(it[2] + it[3])), lambda it: (it[2] - it[3], -it[3])):
         order = sorted(items, key=lambda it: key(it) + (it[0], it[1]))
         table = [[None] * slots for _ in range(G)]
         tA, tB = [0] * slots, [0] * slots
@@ -150,11 +156,53 @@ def gen_idsva_so_items(self):
             table[ln][sl] = (it[0], it[1])
             tA[sl] = max(tA[sl], it[2])
             tB[sl] = max(tB[sl], it[3])
-        cost = sum(450 + 130 * a + 200 * b for a, b in zip(tA, tB))
+        cost = sum(cI + cA * a + cB * b for a, b in zip(tA, tB))
         if best is None or cost < best[0]:
             best = (cost, table, tA, tB)
     _, table, tA, tB = best
     return table, slots, tA, tB
+
+
+def gen_idsva_so_compact(self):
+    """True where the kernels stage the record of a solve in COMPACT form (tuning so_stage): every value once - d2tau_dq2 and d2tau_dqd2 are
+    symmetric in their last two indices, dM_dq in its first and last, and dM_ik/dq_j is structurally zero for j <= min(i, k) - and the dense
+    4 n^3 record is gathered from it through the table grid_so_expand when it leaves for global memory.  Serial chains, LDS-staged form:
+    7-DoF arm 1 372 -> 936 values per solve (8 resident waves per CU instead of 6) and a third fewer LDS stores in the main loops."""
+    want = self.tuning["so_stage"]
+    if want not in ("auto", "compact", "dense"):
+        raise ValueError("tuning['so_stage'] must be auto, compact or dense")
+    ok = self.gen_idsva_so_mode() == "chain" and not self.gen_idsva_so_direct() and self.tuning["so_mapping"] == "balanced" and self.tuning["so_loops"] == "dots"
+    if want == "compact" and not ok:
+        raise NotImplementedError("so_stage=compact needs a serial chain whose record is staged in LDS, so_mapping=balanced and so_loops=dots")
+    return ok and want != "dense"
+
+
+def gen_idsva_so_compact_layout(self):
+    """Offsets of the compact staging record and the expansion table (slot of every element of the dense record [d2tau_dq2 | d2tau_dqd2 | d2tau_dvdq | dM_dq]).
+    q2c / qd2c: [i][tri(b) + a], a <= b, tri(b) = b (b + 1) / 2;  vq: dense [i][a][b];  mqc: [tri(k) + i][j], i <= k (structurally zero for j <= i:
+    those slots are never written and never read - the table sends the elements to the ZERO slot);  then ZERO and a DUMMY slot for predicated-off stores."""
+    n = self.model.n
+    tri = n * (n + 1) // 2
+    off = {"TRI": tri, "Q2": 0, "QD2": n * tri, "VQ": 2 * n * tri, "MQ": 2 * n * tri + n ** 3}
+    off["ZERO"] = off["MQ"] + tri * n
+    off["DUMMY"] = off["ZERO"] + 1
+    off["SIZE"] = (off["DUMMY"] + 1 + 3) // 4 * 4
+    t = lambda b: b * (b + 1) // 2
+    table = []
+    for ten in range(4):
+        for i in range(n):
+            for a in range(n):
+                for b in range(n):
+                    if ten < 2:
+                        table.append((off["Q2"] if ten == 0 else off["QD2"]) + i * tri + t(max(a, b)) + min(a, b))
+                    elif ten == 2:
+                        table.append(off["VQ"] + (i * n + a) * n + b)
+                    else:  # dM_dq[i][j = a][k = b] = d M_ik / d q_j
+                        lo, hi = min(i, b), max(i, b)
+                        table.append(off["ZERO"] if a <= lo else off["MQ"] + (t(hi) + lo) * n + a)
+    assert max(table) < 65536
+    off["TABLE"] = table
+    return off
 
 
 def gen_idsva_so_items_table(self):
@@ -215,6 +263,152 @@ def _so_emit_balanced_main(self, tree):
                 _so_emit(self, "        }\n        if (l != m) {")
                 _so_emit(self, _SO_CASE_C, SUB="va")
                 _so_emit(self, "        }")
+            A("l = ln; va = more; lpar = npar;")
+            A("#pragma unroll")
+            A("for (int r = 0; r < 6; r++) { xS[r] = nS[r]; xP[r] = nP[r]; }")
+            self.gen_add_end_control_flow()
+            self.gen_add_end_control_flow()
+        self.gen_add_end_control_flow()
+
+
+# Folded per-item vectors of the dot-product form of the main loops (tuning so_loops = dots).  Every cross product of the reference's p1..p6
+# terms pairs a vector of joint l (the loop variable) with vectors of the item (c, m); with (a x b) . f = -b . (a x* f) the item side is folded
+# into 6-vectors ONCE per item and a loop step is nothing but dot products with S_l / Pd_l:
+#   joint j = l on the path c..m, ancestor-or-self an = m:
+#     d2tau_dq2[c][an][j]  = xS.gA - xP.d3P        gA = yP x* [T2;0] - yPP x* T1                        (reference: -p1.T2 + p2.T1 - ...)
+#     d2tau_dq2[j][c][an]  = xS.eW                 eW = d2P + d1PP
+#     d2tau_dvdq[j][c][an] = xS.eV                 eV = d2S + 2 d1P
+#   joint j = m, proper ancestor an = l:
+#     d2tau_dvdq[c][j][an] = xS.gC + 2 xP.d4S      gC = d3P - 2 d1P - yS x* [T2;0]     (2 yP x* T1 = 2 (d3P - d1P);  yS x* T1 = d4S)
+#     d2tau_dq2[an][j][c]  = xS.e3                 e3 = eW + yS x* T3
+#     d2tau_dvdq[an][j][c] = xS.e4                 e4 = d3P + yS x* T4
+#     d2tau_dqd2[an][j][j] = 2 xS.d4S   for c = j  (T1.p3 + xS.(S x* T1) with S = yS)
+_SO_FOLD = """
+    T gA[6], gC[6], eW[6], eV[6], e3[6], e4[6];
+    {
+        T t[6]; grid_zero6(t); grid_fxv_peq(t, yPP, T1);
+        #pragma unroll
+        for (int r = 0; r < 6; r++) { gA[r] = -t[r]; gC[r] = d3P[r] - static_cast<T>(2)*d1P[r]; eW[r] = d2P[r] + d1PP[r]; eV[r] = d2S[r] + static_cast<T>(2)*d1P[r]; e3[r] = eW[r]; e4[r] = d3P[r]; }
+        gA[0] += yP[1]*T2[2] - yP[2]*T2[1]; gA[1] += yP[2]*T2[0] - yP[0]*T2[2]; gA[2] += yP[0]*T2[1] - yP[1]*T2[0];
+        gC[0] -= yS[1]*T2[2] - yS[2]*T2[1]; gC[1] -= yS[2]*T2[0] - yS[0]*T2[2]; gC[2] -= yS[0]*T2[1] - yS[1]*T2[0];
+        grid_fxv_peq(e3, yS, T3); grid_fxv_peq(e4, yS, T4);
+    }
+    const T y_d1S = grid_dot6(yS, d1S); // S_m . D1 S_m: the diagonal d2tau_dqd2[c][m][m] and dM_dq[m][c][m]
+"""
+
+
+class _SoStores:
+    """Store statements of the second-order main loops for one staging form.  dense: the record itself, [t][i][a][b] at t n^3 + (i n + a) n + b, symmetric
+    entries written twice; compact (gen_idsva_so_compact_layout): every value once.  `tri_b` is the C++ expression of b (b + 1) / 2."""
+
+    def __init__(self, n, compact_layout=None):
+        self.n, self.L = n, compact_layout
+
+    def sym(self, tensor, i, a, b, tri_b, val):  # d2tau_dq2 / d2tau_dqd2 entry (i; a, b) = (i; b, a), a <= b
+        n = self.n
+        if self.L is not None:
+            return "so[%d + (%s)*%d + (%s) + (%s)] = %s;" % (self.L["Q2" if tensor == "q2" else "QD2"], i, self.L["TRI"], tri_b, a, val)
+        base = 0 if tensor == "q2" else n ** 3
+        return "so[%d + ((%s)*%d + (%s))*%d + (%s)] = so[%d + ((%s)*%d + (%s))*%d + (%s)] = %s;" % (base, i, n, a, n, b, base, i, n, b, n, a, val)
+
+    def vq(self, i, a, b, val):
+        n = self.n
+        return "so[%d + ((%s)*%d + (%s))*%d + (%s)] = %s;" % (self.L["VQ"] if self.L is not None else 2 * n ** 3, i, n, a, n, b, val)
+
+    def mq(self, i, j, k, tri_k, val):  # dM_dq entry [i][j][k] = [k][j][i] = d M_ik / d q_j, i <= k
+        n = self.n
+        if self.L is not None:
+            return "so[%d + ((%s) + (%s))*%d + (%s)] = %s;" % (self.L["MQ"], tri_k, i, n, j, val)
+        return "so[%d + ((%s)*%d + (%s))*%d + (%s)] = so[%d + ((%s)*%d + (%s))*%d + (%s)] = %s;" % (3 * n ** 3, i, n, j, n, k, 3 * n ** 3, k, n, j, n, i, val)
+
+
+def _so_emit_balanced_main_dots(self, tree, compact):
+    """Main loops, balanced mapping (gen_idsva_so_items), dot-product form (see _SO_FOLD); expects the per-lane quantities of _SO_PREP (lane <-> joint) and
+    the records [S | Pd | Pdd | parent] in s_X.  Writes through `so`: the dense record (LDS or global memory) or the compact staging record."""
+    n, G = self.model.n, self.lanes_per_solve
+    table, slots, tA, tB = self.gen_idsva_so_items()
+    st = _SoStores(n, self.gen_idsva_so_compact_layout() if compact else None)
+    A = self.gen_add_code_line
+    A("// balanced mapping: this lane's items (c, m), %d per lane, from the table grid_so_items (emitted with the model constants)" % slots)
+    A("const bool own_lane = active@NOSTORE@;".replace("@NOSTORE@", " && (gravity < static_cast<T>(-1e30))" if self.tuning["debug_stop"] == 30 else ""))
+    A("const T (&oIC)[10] = IC; const T (&oBC)[12] = BC; const T (&oT1)[6] = T1; const T (&oT2)[3] = T2; const T (&oT3)[6] = T3; const T (&oT4)[6] = T4;")
+    A("const T (&oICPd)[6] = ICPd; const T (&oS)[6] = S; const T (&oPd)[6] = Pd;")
+    par = (lambda l: "static_cast<int>(s_X[20*%s + 18])" % l) if tree else (lambda l: "(%s - 1)" % l)
+    tri = lambda v: "((%s)*((%s) + 1) >> 1)" % (v, v)
+    for sl in range(slots):
+        A("{ // item slot %d: path loops of up to %d steps, ancestor loops of up to %d steps" % (sl, tA[sl], tB[sl]), True)
+        A("const int ic = grid_so_items[%d*lane + %d], im = grid_so_items[%d*lane + %d];" % (2 * slots, 2 * sl, 2 * slots, 2 * sl + 1))
+        A("const bool item = ic >= 0; const int c = item ? ic : 0, m = item ? im : 0; const bool own = own_lane && item;")
+        A("const int tc = %s, tm = %s; (void)tc; (void)tm; // c (c + 1) / 2, m (m + 1) / 2: rows of the symmetric (compact) index" % (tri("c"), tri("m")))
+        A("T IC[10], BC[12], T1[6], T2[3], T3[6], T4[6], ICPd[6], S[6], Pd[6]; // joint c's quantities, fetched from its lane")
+        for nm, ln_ in (("IC", 10), ("BC", 12), ("T1", 6), ("T2", 3), ("T3", 6), ("T4", 6), ("ICPd", 6), ("S", 6), ("Pd", 6)):
+            A("#pragma unroll")
+            A("for (int r = 0; r < %d; r++) { %s[r] = __shfl(o%s[r], c, GRID_LANES_PER_SOLVE); }" % (ln_, nm, nm))
+        _so_emit(self, _SO_OPERATORS)
+        _so_emit(self, _SO_FOLD)
+
+        def fetch(dst_s, dst_p, dst_par, lv, decl):
+            A("#pragma unroll")
+            A("for (int r = 0; r < 6; r++) { %s[r] = s_X[20*%s + r]; %s[r] = s_X[20*%s + 6 + r]; }" % (dst_s, lv, dst_p, lv))
+            A("%s%s = %s;" % ("const int " if decl else "", dst_par, par(lv)))
+
+        A("if (own && c != m) { %s } // dM_dq[m][c][m]: the step l = m of the ancestor loop" % st.mq("m", "c", "m", "tm", "y_d1S"))
+        # ---- path loop: joint j = l walks c -> m, ancestor-or-self an = m
+        A("{ // joint j = l walks the path c -> m, ancestor-or-self an = m; the record of the next joint is fetched while this one is worked on", True)
+        A("int l = c, lpar; bool va = true;")
+        A("T xS[6], xP[6];")
+        fetch("xS", "xP", "lpar", "l", False)
+        A("#pragma unroll 1")
+        A("for (int t = 0; t < %d; t++) {" % tA[sl], True)
+        A("const bool more = va && (l != m); const int ln = more ? lpar : l;")
+        A("T nS[6], nP[6];")
+        fetch("nS", "nP", "npar", "ln", True)
+        A("const T s_d3P = grid_dot6(xS, d3P), s_d3S = grid_dot6(xS, d3S), s_eW = grid_dot6(xS, eW), s_eV = grid_dot6(xS, eV);")
+        A("const T vq_ = grid_dot6(xS, gA) - grid_dot6(xP, d3P);")
+        A("const int j = l, an = m, tj = %s; (void)tj;" % tri("l"))
+        A("const bool ok = own && va, ne = ok && (c != j);")
+        A("if (ok) {", True)
+        A(st.sym("q2", "c", "an", "j", "tj", "vq_"))
+        A(st.vq("c", "an", "j", "-s_d3P"))
+        A(st.sym("qd2", "c", "an", "j", "tj", "(an != j) ? -s_d3S : -y_d1S"))
+        self.gen_add_end_control_flow()
+        A("if (ne) {", True)
+        A(st.sym("q2", "j", "an", "c", "tc", "s_eW"))
+        A(st.vq("j", "an", "c", "s_d3P"))
+        A(st.sym("qd2", "j", "an", "c", "tc", "s_d3S"))
+        A(st.vq("j", "c", "an", "s_eV"))
+        self.gen_add_end_control_flow()
+        A("l = ln; va = more; lpar = npar;")
+        A("#pragma unroll")
+        A("for (int r = 0; r < 6; r++) { xS[r] = nS[r]; xP[r] = nP[r]; }")
+        self.gen_add_end_control_flow()
+        self.gen_add_end_control_flow()
+        # ---- ancestor loop: joint j = m, proper ancestor an = l walks parent(m) -> root
+        if tB[sl] > 0:
+            A("{ // joint j = m, proper ancestor an = l walks parent(m) -> root", True)
+            A("int l = %s, lpar; bool va = l >= 0; if (!va) { l = 0; }" % par("m"))
+            A("T xS[6], xP[6];")
+            fetch("xS", "xP", "lpar", "l", False)
+            A("#pragma unroll 1")
+            A("for (int t = 0; t < %d; t++) {" % tB[sl], True)
+            A("const bool more = va && (lpar >= 0); const int ln = more ? lpar : l;")
+            A("T nS[6], nP[6];")
+            fetch("nS", "nP", "npar", "ln", True)
+            A("const T s_d1S = grid_dot6(xS, d1S), s_d3S = grid_dot6(xS, d3S), s_d4S = grid_dot6(xS, d4S), s_eV = grid_dot6(xS, eV), s_e3 = grid_dot6(xS, e3), s_e4 = grid_dot6(xS, e4);")
+            A("const T vq_ = grid_dot6(xS, gC) + static_cast<T>(2)*grid_dot6(xP, d4S);")
+            A("const int j = m, an = l;")
+            A("const bool ok = own && va, ne = ok && (c != j);")
+            A("if (ok) {", True)
+            A(st.vq("c", "j", "an", "vq_"))
+            A(st.sym("q2", "an", "j", "c", "tc", "s_e3"))
+            A(st.vq("an", "j", "c", "s_e4"))
+            A(st.mq("an", "j", "c", "tc", "s_d4S"))
+            A(st.sym("qd2", "an", "j", "c", "tc", "(c != j) ? s_d3S : static_cast<T>(2)*s_d4S"))
+            self.gen_add_end_control_flow()
+            A("if (ne) {", True)
+            A(st.vq("an", "c", "j", "s_eV"))
+            A(st.mq("an", "c", "j", "tm", "s_d1S"))
+            self.gen_add_end_control_flow()
             A("l = ln; va = more; lpar = npar;")
             A("#pragma unroll")
             A("for (int r = 0; r < 6; r++) { xS[r] = nS[r]; xP[r] = nP[r]; }")
@@ -362,7 +556,7 @@ def _so_emit(self, text, **subs):
         self.gen_add_code_line(line)
 
 
-def _so_inner_header(self):
+def _so_inner_header(self, compact=False):
     n = self.model.n
     form = "serial revolute chains; computed in the frame of the tip link" if self.gen_idsva_so_mode() == "chain" else \
         "kinematic trees of revolute joints; computed in the base frame, kinematics and subtree composites handed level by level through LDS"
@@ -370,19 +564,21 @@ def _so_inner_header(self):
                           [form + ", lane c owns the subtree joint of every (joint, ancestor, subtree) triple",
                            "so = [d2tau_dq2 | d2tau_dqd2 | d2tau_dvdq | dM_dq], each n x n x n with [i][j][k] at i*n*n + j*n + k (reference algorithms/_idsva_so.py:204-208);",
                            "d2tau_dvdq[i][j][k] = d2 tau_i / dq_j dqd_k, dM_dq[i][j][k] = d M_ik / dq_j.  Every entry is written exactly once (trees: after a zero fill of the record by the same wave); `so` may be LDS" +
-                           (" or global memory" if self.gen_idsva_so_mode() == "chain" else "")],
-                          ["so is the output record of this solve (4*NUM_JOINTS^3 values)", "s_qd is the vector of joint velocities in LDS",
+                           (" or global memory" if self.gen_idsva_so_mode() == "chain" else "")] +
+                          (["COMPACT form: `so` is the staging record of IDSVA_SO_STAGE_PER_SOLVE values that holds every value once (symmetric entries, no structural zeros); the dense",
+                            "record is gathered from it through the table grid_so_expand (what the kernels do when the record leaves for global memory)"] if compact else []),
+                          [("so is the compact staging record of this solve (IDSVA_SO_STAGE_PER_SOLVE values)" if compact else "so is the output record of this solve (4*NUM_JOINTS^3 values)"), "s_qd is the vector of joint velocities in LDS",
                            "s_qdd is the vector of joint accelerations in LDS", "s_X is this solve's scratch: compact X(q) storage on entry; it is overwritten by the per-joint records",
                            "d_robotModel is the pointer to the initialized model specific helpers on the GPU", "gravity is the gravity constant",
                            "lane is the caller's lane index inside the solve's lane group", "active is false for lane groups without a solve (they compute but do not store)"], None)
     self.gen_add_code_line("template <typename T>")
     self.gen_add_code_line("__device__ __forceinline__")
-    self.gen_add_code_line("void idsva_so_inner(T *__restrict__ so, const T *__restrict__ s_qd, const T *__restrict__ s_qdd, T *__restrict__ s_X, const robotModel<T> *d_robotModel, const T gravity, const int lane, const bool active) {", True)
+    self.gen_add_code_line("void idsva_so_inner" + ("_compact" if compact else "") + "(T *__restrict__ so, const T *__restrict__ s_qd, const T *__restrict__ s_qdd, T *__restrict__ s_X, const robotModel<T> *d_robotModel, const T gravity, const int lane, const bool active) {", True)
 
 
-def gen_idsva_so_inner_chain(self, use_thread_group=False):
+def gen_idsva_so_inner_chain(self, use_thread_group=False, compact=False):
     n = self.model.n
-    _so_inner_header(self)
+    _so_inner_header(self, compact)
     _emit_link_constants_load(self)
     _emit_chain_decls(self)
     for i in range(self.tip_L - 1, -1, -1):
@@ -392,7 +588,11 @@ def gen_idsva_so_inner_chain(self, use_thread_group=False):
     self.gen_add_code_line("const T qdd = (lane < %d) ? s_qdd[lane] : static_cast<T>(0);" % n)
     _emit_bias(self, True)
     _so_emit(self, _SO_PREP, PARENT="")
-    _so_emit(self, """
+    if compact:
+        L = self.gen_idsva_so_compact_layout()
+        self.gen_add_code_line("if (lane == 0) { so[%d] = static_cast<T>(0); } // the ZERO slot: what the structurally zero entries of dM_dq expand from" % L["ZERO"])
+    else:
+        _so_emit(self, """
 // structurally zero entries of dM_dq: dM_ik/dq_j with j <= min(i, k); the owner lane (largest index) writes them first
 #pragma unroll 1
 for (int b = 0; b < @N@; b++) {
@@ -402,7 +602,10 @@ for (int b = 0; b < @N@; b++) {
 }
 """)
     if self.tuning["so_mapping"] == "balanced":
-        _so_emit_balanced_main(self, tree=False)
+        if self.tuning["so_loops"] == "dots":
+            _so_emit_balanced_main_dots(self, tree=False, compact=compact)
+        else:
+            _so_emit_balanced_main(self, tree=False)
         self.gen_add_end_function()
         return
     _so_emit(self, """
@@ -526,7 +729,10 @@ def gen_idsva_so_inner_tree(self, use_thread_group=False):
     self.gen_add_end_control_flow()
     _so_emit(self, _SO_PREP, PARENT="rec[18] = static_cast<T>(par); // parent joint id (-1: base), read by the balanced main loops")
     if self.tuning["so_mapping"] == "balanced":
-        _so_emit_balanced_main(self, tree=True)
+        if self.tuning["so_loops"] == "dots":
+            _so_emit_balanced_main_dots(self, tree=True, compact=False)
+        else:
+            _so_emit_balanced_main(self, tree=True)
         self.gen_add_end_function()
         return
     sub = lambda jv: "(c >= %s && c < %s + grid_so_tree_topology[%d*%s + 2])" % (jv, jv, K, jv)
@@ -550,9 +756,10 @@ for (int m = 0; m < @N@; m++) {""")
     self.gen_add_end_function()
 
 
-def gen_idsva_so_device(self, use_thread_group=False, use_qdd_input=False):
+def gen_idsva_so_device(self, use_thread_group=False, use_qdd_input=False, compact=False):
     n = self.model.n
-    params = ["so is the output record of this solve: 4*NUM_JOINTS^3 values [d2tau_dq2 | d2tau_dqd2 | d2tau_dvdq | dM_dq] (global or LDS memory)",
+    params = ["so is the compact staging record of this solve in LDS: IDSVA_SO_STAGE_PER_SOLVE values (see idsva_so_inner_compact)" if compact else
+              "so is the output record of this solve: 4*NUM_JOINTS^3 values [d2tau_dq2 | d2tau_dqd2 | d2tau_dvdq | dM_dq] (global or LDS memory)",
               "s_q is the vector of joint positions in LDS", "s_qd is the vector of joint velocities in LDS"]
     if use_qdd_input:
         params.append("s_qdd is the vector of joint accelerations in LDS")
@@ -562,14 +769,14 @@ def gen_idsva_so_device(self, use_thread_group=False, use_qdd_input=False):
                           ["all lanes of the solve's lane group must call it" + ("" if use_qdd_input else "; qdd = 0")], params, None)
     self.gen_add_code_line("template <typename T>")
     self.gen_add_code_line("__device__ __forceinline__")
-    self.gen_add_code_line("void idsva_so_device(T *so, const T *s_q, const T *s_qd, " + ("const T *s_qdd, " if use_qdd_input else "") +
+    self.gen_add_code_line("void idsva_so_device" + ("_compact" if compact else "") + "(T *so, const T *s_q, const T *s_qd, " + ("const T *s_qdd, " if use_qdd_input else "") +
                            "T *s_scratch, const robotModel<T> *d_robotModel, const T gravity, const int lane, const bool active) {", True)
     self.gen_add_code_line("T *s_X = s_scratch;")
     if not use_qdd_input:
         self.gen_add_code_line("T *s_qdd = &s_scratch[%d];" % (self.gen_idsva_so_rec() * n))
         self.gen_add_code_line("if (lane < %d) { s_qdd[lane] = static_cast<T>(0); }" % n)
     self.gen_load_update_XImats_helpers_function_call(use_thread_group)
-    self.gen_idsva_so_inner_function_call(use_thread_group, use_qdd_input)
+    self.gen_idsva_so_inner_function_call(use_thread_group, use_qdd_input, compact=compact)
     self.gen_add_end_function()
 
 
@@ -598,8 +805,9 @@ def gen_idsva_so_kernel(self, use_thread_group=False, use_qdd_input=False, singl
     self.gen_kernel_prologue("IDSVA_SO_LDS_PER_SOLVE", "IDSVA_SO_MAX_SOLVES_PER_BLOCK")
     self.gen_add_code_line("T *s_q_qd_u = s_mem; T *s_q = s_q_qd_u; T *s_qd = &s_q_qd_u[%d]; T *s_qdd = &s_q_qd_u[%d]; T *s_scratch = &s_mem[%d]; (void)s_qdd;" % (n, 2 * n, pad3n))
     direct = self.gen_idsva_so_direct()
+    compact = self.gen_idsva_so_compact()
     if not direct:
-        self.gen_add_code_line("T *s_idsva_so = &s_out_all[grp*%d]; // this solve's output record, staged in LDS" % stage)
+        self.gen_add_code_line("T *s_idsva_so = &s_out_all[grp*%d]; // this solve's output record, staged in LDS%s" % (stage, " in compact form (every value once)" if compact else ""))
     if single_call_timing:
         self.gen_add_code_line("const int k = 0; const int kc = 0; const bool valid = (blockIdx.x + blockIdx.y == 0) && (grp == 0); const int lane = lane_id;")
         self.gen_add_code_line("if (!valid) {return;}")
@@ -617,13 +825,22 @@ def gen_idsva_so_kernel(self, use_thread_group=False, use_qdd_input=False, singl
         self.gen_add_code_line("idsva_so_device<T>(&d_idsva_so[static_cast<size_t>(kc)*%d], s_q, s_qd, " % (4 * n3) + ("s_qdd, " if use_qdd_input else "") + "s_scratch, d_robotModel, gravity, lane, valid);")
         self.gen_add_sync(use_thread_group)
     else:
-        self.gen_add_code_line("idsva_so_device<T>(s_idsva_so, s_q, s_qd, " + ("s_qdd, " if use_qdd_input else "") + "s_scratch, d_robotModel, gravity, lane, true);")
+        self.gen_add_code_line("idsva_so_device" + ("_compact" if compact else "") + "<T>(s_idsva_so, s_q, s_qd, " + ("s_qdd, " if use_qdd_input else "") + "s_scratch, d_robotModel, gravity, lane, true);")
     if single_call_timing:
         self.gen_add_end_control_flow()
     if direct:
         pass
     elif single_call_timing:
-        self.gen_kernel_save_result_single_timing("idsva_so", 4 * n3, use_thread_group)
+        if compact:
+            self.gen_add_sync(use_thread_group)
+            self.gen_add_code_line("// save down to global: the dense record gathered from the compact staging")
+            self.gen_add_parallel_loop("ind", str(4 * n3), use_thread_group)
+            self.gen_add_code_line("d_idsva_so[ind] = s_idsva_so[grid_so_expand[ind]];")
+            self.gen_add_end_control_flow()
+        else:
+            self.gen_kernel_save_result_single_timing("idsva_so", 4 * n3, use_thread_group)
+    elif compact:
+        self.gen_kernel_save_result_expanded("idsva_so", 4 * n3, stage, "grid_so_expand", use_thread_group)
     else:
         self.gen_kernel_save_result("idsva_so", 4 * n3, 4 * n3, use_thread_group)
     if not single_call_timing:
@@ -683,6 +900,10 @@ def gen_idsva_so(self, use_thread_group=False):
     self.gen_idsva_so_inner(use_thread_group, True)
     self.gen_idsva_so_device(use_thread_group, False)
     self.gen_idsva_so_device(use_thread_group, True)
+    if self.gen_idsva_so_compact():  # what the kernels run; the dense-record functions above stay for callers that hand in a record of their own
+        self.gen_idsva_so_inner(use_thread_group, True, compact=True)
+        self.gen_idsva_so_device(use_thread_group, False, compact=True)
+        self.gen_idsva_so_device(use_thread_group, True, compact=True)
     for qdd in (True, False):
         for timing in (True, False):
             self.gen_idsva_so_kernel(use_thread_group, qdd, timing)

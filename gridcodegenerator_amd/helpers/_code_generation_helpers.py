@@ -249,3 +249,33 @@ def gen_kernel_save_result(self, store_to_name, stride, amount, use_thread_group
                              "{ const int e = (total & ~3) + wl; if (wl < 3 && e < total) { dst[e] = src[e]; } }"])
     self.gen_add_end_control_flow()
     self.gen_add_sync(use_thread_group)
+
+
+def gen_kernel_save_result_expanded(self, store_to_name, amount, stage, table_name, use_thread_group=False, load_from_name=None):
+    """Compact LDS staging -> dense global record.  As gen_kernel_save_result (the lane groups of a wave own consecutive solves, their staging records
+    are contiguous in LDS, the wave's output is one contiguous span of global memory written 16 bytes per lane and trip), but a staging record holds
+    every value of a solve ONCE (`stage` values) and the dense record (`amount` values, a multiple of 4) is gathered from it through `table_name`
+    (unsigned short slot per dense element, the same for every solve): a lane reads the four slots of its 16-byte piece once (8 bytes) and moves that
+    piece of every solve of the wave."""
+    assert int(amount) % 4 == 0
+    if load_from_name is None:
+        load_from_name = "s_" + store_to_name
+    self.gen_add_sync(use_thread_group)
+    self.gen_add_code_line("// save down to global: wave-cooperative, coalesced; the dense record is gathered from the compact staging through " + table_name)
+    self.gen_add_code_line("{", True)
+    self.gen_add_code_lines(["const int gw0 = grp & ~(GRID_SOLVES_PER_WAVE-1); // first lane group of this wave",
+                             "int nv = NUM_TIMESTEPS_OUT - (k - grp + gw0); { const int ng = gpb - gw0; nv = nv < ng ? nv : ng; nv = nv < GRID_SOLVES_PER_WAVE ? nv : GRID_SOLVES_PER_WAVE; nv = nv > 0 ? nv : 0; } // (a wave whose lane groups are all past the end of the batch writes nothing)",
+                             "const T *src = " + load_from_name + " - (grp - gw0)*" + str(stage) + ";",
+                             "T *dst = &d_" + store_to_name + "[static_cast<size_t>(k - grp + gw0)*" + str(amount) + "];",
+                             "const int wl = tid & 63;",
+                             "int wn = gpb*GRID_LANES_PER_SOLVE - (tid & ~63); wn = wn < 64 ? wn : 64; // lanes of this wave that take part (the last wave of a block may be partial)",
+                             ("if (NUM_TIMESTEPS_OUT < 0) " if self.tuning["no_store"] else "") + "for (int g = wl; g < " + str(int(amount) // 4) + "; g += wn) { // 16-byte piece g of every record", ])
+    self.indent_level += 1
+    self.gen_add_code_lines(["unsigned short ix[4]; __builtin_memcpy(ix, __builtin_assume_aligned(&" + table_name + "[4*g], 8), 8);",
+                             "#pragma unroll",
+                             "for (int s = 0; s < GRID_SOLVES_PER_WAVE; s++) {",
+                             "    if (s < nv) { const T *rec = src + s*" + str(stage) + "; T tmp[4] = {rec[ix[0]], rec[ix[1]], rec[ix[2]], rec[ix[3]]}; grid_store4(dst + static_cast<size_t>(s)*" + str(amount) + " + 4*g, tmp); }",
+                             "}"])
+    self.gen_add_end_control_flow()
+    self.gen_add_end_control_flow()
+    self.gen_add_sync(use_thread_group)

@@ -158,6 +158,10 @@ def gen_model_constant_table(self):
         it = self.gen_idsva_so_items_table()
         self.gen_add_code_line("// work items (c, m) of the second-order main loops, [lane][slot] (algorithms/_idsva_so.py: gen_idsva_so_items)")
         self.gen_add_code_line("__device__ const int grid_so_items[%d] = {%s};" % (len(it), ", ".join(str(int(x)) for x in it)))
+    if self.gen_idsva_so_mode() is not None and self.gen_idsva_so_compact():
+        L = self.gen_idsva_so_compact_layout()
+        self.gen_add_code_line("// slot of every element of the dense second-order record in the compact staging record (algorithms/_idsva_so.py: gen_idsva_so_compact_layout)")
+        self.gen_add_code_line("__device__ __attribute__((aligned(16))) const unsigned short grid_so_expand[%d] = {%s};" % (len(L["TABLE"]), ", ".join(str(int(x)) for x in L["TABLE"])))
     for ctype, sfx in (("float", "f"), ("double", "")):
         self.gen_add_code_line("__device__ const %s grid_model_constants_%s[%d] = {" % (ctype, ctype, len(vals)), True)
         for k in range(0, len(vals), 6):
