@@ -27,6 +27,8 @@ TUNING_DEFAULTS = {
     "so_mapping": "balanced",   # balanced | subtree: work distribution of the idsva_so main loops (algorithms/_idsva_so.py: gen_idsva_so_items)
     "so_loops": "dots",         # dots | mxm: loop bodies of the balanced idsva_so main loops - every cross product folded into per-item vectors, a step is dot products
                                 # only (algorithms/_idsva_so.py: _SO_FOLD), or the round-2 bodies with motion cross products per step
+    "so_fused": True,           # fdsva_so of serial chains: the forward-dynamics-gradient inner goes straight on to the idsva_so main loops with the per-joint quantities it holds
+                                # in registers (one pass over frames, velocities and composites instead of two; algorithms/_tip_frame_gradient.py: with_so)
     "so_stage": "auto",         # auto | compact | dense: LDS staging of the idsva_so record - compact = every value once (symmetric entries, no structural zeros), expanded
                                 # through the table grid_so_expand on the way out (auto: serial chains whose record is staged in LDS)
     "min_lanes": 8,             # smallest lane group (8 | 16 | 32 | 64): wider groups than the joint count needs leave lanes idle in the first-order kernels but
@@ -111,7 +113,7 @@ class GRiDCodeGenerator:
         gen_forward_dynamics_host, gen_forward_dynamics, \
         gen_aba_inner_temp_mem_size, gen_aba_inner_function_call, gen_aba_inner, gen_aba_device, gen_aba_kernel, gen_aba_host, gen_aba, \
         gen_idsva_so_available, gen_idsva_so_mode, gen_idsva_so_direct, gen_idsva_so_compact, gen_idsva_so_compact_layout, gen_idsva_so_rec, gen_idsva_so_tree_tables, gen_idsva_so_items, gen_idsva_so_items_table, gen_idsva_so_lds_layout, gen_idsva_so_inner_temp_mem_size, gen_idsva_so_inner_function_call, gen_idsva_so_inner, gen_idsva_so_device, gen_idsva_so_kernel, gen_idsva_so_host, gen_idsva_so, \
-        gen_fdsva_so_inner_temp_mem_size, gen_fdsva_so_stage_size, gen_fdsva_so_inner, gen_fdsva_so_device, gen_fdsva_so_kernel, gen_fdsva_so_host, gen_fdsva_so, \
+        gen_fdsva_so_inner_temp_mem_size, gen_fdsva_so_stage_size, gen_fdsva_so_fused_layout, gen_fdsva_so_lds_per_solve, gen_fdsva_so_fused_device, gen_fdsva_so_inner, gen_fdsva_so_device, gen_fdsva_so_kernel, gen_fdsva_so_host, gen_fdsva_so, \
         gen_inverse_dynamics_gradient_inner_temp_mem_size, gen_inverse_dynamics_gradient_kernel_max_temp_mem_size, \
         gen_inverse_dynamics_gradient_inner_function_call, gen_inverse_dynamics_gradient_inner, gen_dc_du_to_lds, gen_gradient_slots, gen_gradient_outputs_decl, \
         gen_inverse_dynamics_gradient_device, gen_inverse_dynamics_gradient_kernel, gen_inverse_dynamics_gradient_host, gen_inverse_dynamics_gradient, \
@@ -119,7 +121,7 @@ class GRiDCodeGenerator:
         gen_forward_dynamics_gradient_inner_python, gen_forward_dynamics_gradient_device, gen_forward_dynamics_gradient_stream_device, gen_forward_dynamics_gradient_kernel, \
         gen_forward_dynamics_gradient_host, gen_forward_dynamics_gradient, gen_forward_dynamics_gradient_device_function_call, \
         gen_tip_frame_link_constants, gen_tip_frame_joint_offset, gen_tip_frame_library, gen_forward_dynamics_gradient_inner_tip, \
-        gen_forward_dynamics_gradient_inner_tip_function_call, gen_tip_frame_gradient, \
+        gen_forward_dynamics_gradient_inner_tip_function_call, gen_tip_frame_gradient, gen_tip_frame_fused_so, \
         gen_inverse_dynamics_inner_tip, gen_inverse_dynamics_gradient_inner_tip, gen_forward_dynamics_inner_tip, gen_direct_minv_inner_tip, gen_tip_frame_components, \
         gen_branch_frame_plan, gen_branch_frame_constants, gen_branch_frame_library, gen_branch_frame_components, gen_forward_dynamics_gradient_inner_branch, gen_forward_dynamics_gradient_inner_branch_stream, \
         gen_forward_dynamics_gradient_inner_branch_function_call
@@ -315,11 +317,11 @@ class GRiDCodeGenerator:
                                      "const int IDSVA_SO_STAGE_PER_SOLVE = %d;" % stg_,
                                      "const int IDSVA_SO_MAX_SOLVES_PER_BLOCK = IDSVA_SO_SUGGESTED_THREADS/GRID_LANES_PER_SOLVE; // lane groups of larger blocks retire",
                                      "const int IDSVA_SO_DYNAMIC_SHARED_MEM_COUNT = IDSVA_SO_MAX_SOLVES_PER_BLOCK*(IDSVA_SO_LDS_PER_SOLVE + IDSVA_SO_STAGE_PER_SOLVE);"])
-            st_ = self.gen_fdsva_so_stage_size()
+            fsl_, st_ = self.gen_fdsva_so_lds_per_solve()
             # block size of fdsva_so: the number of lane groups per block that lets the most solves be resident on a CU (its LDS holds the workspace,
             # df/du and the 4 n^3 idsva_so tensors of every solve); ties go to the smaller block = more waves (measured on the 7-DoF arm, 65 536
             # solves: 64 threads 707 us, 48: 652, 32: 606, 24: 596)
-            per = (lds["TOTAL"] + st_) * 4
+            per = (fsl_ + st_) * 4
             best_g, best_res = 1, 0
             for g_ in range(max(1, -(-24 // G)), max(1, 64 // G) + 1):  # (at least 24 lanes of a wave in use)
                 res = min(155 * 1024 // (g_ * per), 8) * g_  # (blocks of at most one wave; the kernel holds > 168 VGPRs: at most 8 waves per CU)
@@ -327,9 +329,10 @@ class GRiDCodeGenerator:
                     best_g, best_res = g_, res
             fd_so_threads = best_g * G
             self.gen_add_code_lines(["const int FDSVA_SO_SUGGESTED_THREADS = %d; // fdsva_so keeps the 4 n^3 idsva_so tensors of every solve in LDS: fewer solves per block" % fd_so_threads,
-                                     "const int FDSVA_SO_STAGE_PER_SOLVE = " + str(st_) + "; // df/du (2 n^2, padded) + idsva_so (4 n^3), behind the block's slices",
+                                     "const int FDSVA_SO_LDS_PER_SOLVE = " + str(fsl_) + "; // slice of the fdsva_so kernels" + (": per-joint records | df/du | M^-1 (the gradient works inside the staging record)" if fsl_ != lds["TOTAL"] else " (the general slice)"),
+                                     "const int FDSVA_SO_STAGE_PER_SOLVE = " + str(st_) + "; // " + ("the idsva_so tensors" if fsl_ != lds["TOTAL"] else "df/du (2 n^2, padded) + the idsva_so tensors") + ", behind the block's slices",
                                      "const int FDSVA_SO_MAX_SOLVES_PER_BLOCK = FDSVA_SO_SUGGESTED_THREADS/GRID_LANES_PER_SOLVE;",
-                                     "const int FDSVA_SO_DYNAMIC_SHARED_MEM_COUNT = FDSVA_SO_MAX_SOLVES_PER_BLOCK*(GRID_LDS_PER_SOLVE + FDSVA_SO_STAGE_PER_SOLVE);"])
+                                     "const int FDSVA_SO_DYNAMIC_SHARED_MEM_COUNT = FDSVA_SO_MAX_SOLVES_PER_BLOCK*(FDSVA_SO_LDS_PER_SOLVE + FDSVA_SO_STAGE_PER_SOLVE);"])
         self.gen_add_code_lines(["// dynamic LDS (bytes) a launch with `threads` threads per block needs: one slice + one staging record per lane group of the block.",
                                  "// The host wrappers size their launches with it (the *_DYNAMIC_SHARED_MEM_COUNT constants are this amount for SUGGESTED_THREADS in",
                                  "// elements of T; a block may not exceed the CU's 160 KB: large robots in double precision need fewer threads per block)",

@@ -184,6 +184,16 @@ def gen_fdsva_so_device(self, use_thread_group=False):
     self.gen_add_code_line("void fdsva_so_device(T *df2, T *s_df_du, T *s_idsva_so, const T *s_q, const T *s_qd, const T *s_u, T *s_work, const robotModel<T> *d_robotModel, const T gravity, const int lane, const bool active) {", True)
     self.gen_add_code_line("T *s_qdd = &s_work[GRID_OFF_QDD]; T *s_Minv = &s_work[GRID_OFF_MINV];")
     self.gen_add_code_line("// (the gradient comes first: it uses the workspace freely - the M^-1 slot as scratch, on branched robots its own layout - so qdd and M^-1 are produced after it)")
+    if self.gen_tip_frame_fused_so():
+        self.gen_add_code_line("// (serial chains: the tip-frame inner of the gradient leaves qdd and M^-1 behind and goes straight on to the idsva_so main loops with the per-joint")
+        self.gen_add_code_line("//  quantities it holds in registers - one pass over frames, velocities and composites where the reference composes four calls, algorithms/_fdsva_so.py:147-156)")
+        self.gen_add_code_line("T *s_X = &s_work[GRID_OFF_X]; T *s_U = &s_work[GRID_OFF_U];")
+        self.gen_load_update_XImats_helpers_function_call(use_thread_group)
+        self.gen_add_code_line("forward_dynamics_gradient_inner_tip_so<T>(s_df_du, s_qd, s_u, s_X, s_U, s_Minv, d_robotModel, gravity, lane, s_qdd, s_Minv, s_idsva_so, s_X, %s);" % ("active" if self.gen_idsva_so_direct() else "true"))
+        self.gen_add_sync(use_thread_group)
+        self.gen_add_code_line("fdsva_so_inner<T>(df2, s_idsva_so, s_Minv, s_df_du, lane, active);")
+        self.gen_add_end_function()
+        return
     if self.tip_frame and not getattr(self, "branch_frame", False):
         self.gen_add_code_line("// (robots whose gradient runs the tip-frame inner: it leaves qdd and M^-1 behind - one pass instead of three)")
         self.gen_add_code_line("forward_dynamics_gradient_device<T>(s_df_du, s_q, s_qd, s_u, s_work, d_robotModel, gravity, lane, s_qdd, s_Minv);")
@@ -202,10 +212,68 @@ def gen_fdsva_so_device(self, use_thread_group=False):
     self.gen_add_end_function()
 
 
+def gen_fdsva_so_fused_layout(self):
+    """LDS of the fdsva_so KERNELS where the fused inner runs (gen_tip_frame_fused_so, records staged in LDS).  What is live when the idsva_so record is
+    written and contracted - the per-joint records [S | Pd | Pdd], df/du and M^-1 - makes up the slice; everything the gradient works with before that
+    (inputs, X(q), its hand-off records, M) lives INSIDE the staging record of the idsva_so tensors, which is not written until the gradient is done.
+    7-DoF arm: 300 + 936 values per solve instead of 372 + 1 036 -> 8 resident waves per CU instead of 7.  None where the kernels keep the general slice."""
+    if not self.gen_tip_frame_fused_so() or self.gen_idsva_so_direct():
+        return None
+    n = self.model.n
+    pad4 = lambda x: (x + 3) // 4 * 4
+    stage = self.gen_idsva_so_compact_layout()["SIZE"] if self.gen_idsva_so_compact() else 4 * n ** 3
+    L = {"REC": 0, "DF_DU": 20 * n, "MINV": 20 * n + pad4(2 * n * n)}
+    sl = L["MINV"] + n * self.minv_ld
+    if (sl // 4) % 2 == 0:
+        sl += 4
+    L["SLICE"], L["STAGE"] = sl, stage
+    L["IN"] = 0
+    L["X"] = pad4(3 * n)
+    L["G"] = L["X"] + 20 * n
+    L["M"] = L["G"] + pad4(self.tip_rec * n)
+    if L["M"] + n * self.minv_ld > stage:
+        return None
+    return L
+
+
+def gen_fdsva_so_lds_per_solve(self):
+    """(slice, staging) values per solve of the fdsva_so kernels."""
+    F = self.gen_fdsva_so_fused_layout()
+    if F is not None:
+        return F["SLICE"], F["STAGE"]
+    return self.gen_lds_layout()["TOTAL"], self.gen_fdsva_so_stage_size()
+
+
+def gen_fdsva_so_fused_device(self, use_thread_group=False):
+    """The kernels' form of fdsva_so_device with the compact LDS layout of gen_fdsva_so_fused_layout."""
+    n = self.model.n
+    F = self.gen_fdsva_so_fused_layout()
+    self.gen_add_func_doc("Second Order of Forward Dynamics with Spatial Vector Algebra (lane-group cooperative): what the fdsva_so kernels run",
+                          ["as fdsva_so_device, with the kernels' own LDS layout: the gradient works inside the staging record of the idsva_so tensors (not written until it is done),",
+                           "the slice holds only what is live afterwards: per-joint records, df/du, M^-1; all lanes of the solve's lane group must call it"],
+                          ["df2 is the output record of this solve: 4*NUM_JOINTS^3 values (global or LDS memory)",
+                           "s_slice is this solve's LDS slice of FDSVA_SO_LDS_PER_SOLVE elements",
+                           "s_stage is this solve's staging record of FDSVA_SO_STAGE_PER_SOLVE elements; q | qd | u are in its first 3*NUM_JOINTS elements on entry",
+                           "d_robotModel is the pointer to the initialized model specific helpers on the GPU (XImats, topology_helpers, etc.)",
+                           "gravity is the gravity constant", "lane is the caller's lane index inside the solve's lane group", "active is false for lane groups without a solve"], None)
+    self.gen_add_code_line("template <typename T>")
+    self.gen_add_code_line("__device__ __forceinline__")
+    self.gen_add_code_line("void fdsva_so_fused_device(T *df2, T *s_slice, T *s_stage, const robotModel<T> *d_robotModel, const T gravity, const int lane, const bool active) {", True)
+    self.gen_add_code_line("const T *s_q = &s_stage[%d]; const T *s_qd = &s_stage[%d]; const T *s_u = &s_stage[%d];" % (F["IN"], F["IN"] + n, F["IN"] + 2 * n))
+    self.gen_add_code_line("T *s_X = &s_stage[%d]; T *s_G = &s_stage[%d]; T *s_M = &s_stage[%d]; // the gradient's working set, inside the (not yet written) idsva_so record" % (F["X"], F["G"], F["M"]))
+    self.gen_add_code_line("T *s_rec = &s_slice[%d]; T *s_df_du = &s_slice[%d]; T *s_Minv = &s_slice[%d];" % (F["REC"], F["DF_DU"], F["MINV"]))
+    self.gen_load_update_XImats_helpers_function_call(use_thread_group)
+    self.gen_add_code_line("forward_dynamics_gradient_inner_tip_so<T>(s_df_du, s_qd, s_u, s_X, s_G, s_M, d_robotModel, gravity, lane, static_cast<T *>(nullptr), s_Minv, s_stage, s_rec, true);")
+    self.gen_add_sync(use_thread_group)
+    self.gen_add_code_line("fdsva_so_inner<T>(df2, s_stage, s_Minv, s_df_du, lane, active);")
+    self.gen_add_end_function()
+
+
 def gen_fdsva_so_kernel(self, use_thread_group=False, single_call_timing=False):
     n = self.model.n
     n3 = n * n * n
     stage = self.gen_fdsva_so_stage_size()
+    F = self.gen_fdsva_so_fused_layout()
     func_params = ["d_df2 is the output: 4*NUM_JOINTS^3 values per solve, [d2a_dqdq | d2a_dvdv | d2a_dvdq | d2a_dtdq]",
                    "d_q_qd_u is the vector of joint positions, velocities, and input torques", "stride_q_qd_u is the stride between each q, qd, u",
                    "d_robotModel is the pointer to the initialized model specific helpers on the GPU (XImats, topology_helpers, etc.)",
@@ -223,9 +291,13 @@ def gen_fdsva_so_kernel(self, use_thread_group=False, single_call_timing=False):
     self.gen_add_code_line("template <typename T>")
     self.gen_add_code_line("__global__ GRID_LAUNCH_BOUNDS")
     self.gen_add_code_line(func_def, True)
-    self.gen_kernel_prologue("GRID_LDS_PER_SOLVE", "FDSVA_SO_MAX_SOLVES_PER_BLOCK")
-    self.gen_add_code_lines(["T *s_q_qd_u = &s_mem[GRID_OFF_IN]; T *s_q = s_q_qd_u; T *s_qd = &s_q_qd_u[%d]; T *s_u = &s_q_qd_u[%d];" % (n, 2 * n),
-                             "T *s_df_du = &s_out_all[grp*%d];" % stage + ("" if direct else " T *s_idsva_so = s_df_du + %d;" % ((2 * n * n + 3) // 4 * 4))])
+    self.gen_kernel_prologue("FDSVA_SO_LDS_PER_SOLVE", "FDSVA_SO_MAX_SOLVES_PER_BLOCK")
+    if F is not None:
+        self.gen_add_code_lines(["T *s_stage = &s_out_all[grp*%d]; // staging record of the idsva_so tensors; until they are written it holds the inputs and the gradient's working set" % F["STAGE"],
+                                 "T *s_q_qd_u = &s_stage[%d];" % F["IN"]])
+    else:
+        self.gen_add_code_lines(["T *s_q_qd_u = &s_mem[GRID_OFF_IN]; T *s_q = s_q_qd_u; T *s_qd = &s_q_qd_u[%d]; T *s_u = &s_q_qd_u[%d];" % (n, 2 * n),
+                                 "T *s_df_du = &s_out_all[grp*%d];" % stage + ("" if direct else " T *s_idsva_so = s_df_du + %d;" % ((2 * n * n + 3) // 4 * 4))])
     if single_call_timing:
         self.gen_add_code_line("const int k = 0; const int kc = 0; const bool valid = (blockIdx.x + blockIdx.y == 0) && (grp == 0); const int lane = lane_id;")
         self.gen_add_code_line("if (!valid) {return;}")
@@ -237,7 +309,10 @@ def gen_fdsva_so_kernel(self, use_thread_group=False, single_call_timing=False):
     self.gen_add_code_line("// compute; the record of solve k goes straight to global memory")
     if direct:
         self.gen_add_code_line("T *s_idsva_so = &d_idsva_so[static_cast<size_t>(kc)*%d]; // (global workspace; lane groups without a solve never write through it)" % (4 * n3))
-    self.gen_add_code_line("fdsva_so_device<T>(&d_df2[static_cast<size_t>(kc)*%d], s_df_du, s_idsva_so, s_q, s_qd, s_u, s_mem, d_robotModel, gravity, lane, valid);" % (4 * n3))
+    if F is not None:
+        self.gen_add_code_line("fdsva_so_fused_device<T>(&d_df2[static_cast<size_t>(kc)*%d], s_mem, s_stage, d_robotModel, gravity, lane, valid);" % (4 * n3))
+    else:
+        self.gen_add_code_line("fdsva_so_device<T>(&d_df2[static_cast<size_t>(kc)*%d], s_df_du, s_idsva_so, s_q, s_qd, s_u, s_mem, d_robotModel, gravity, lane, valid);" % (4 * n3))
     self.gen_add_sync(use_thread_group)
     if single_call_timing:
         self.gen_add_end_control_flow()
@@ -276,7 +351,7 @@ def gen_fdsva_so_host(self, mode=0):
     self.gen_add_code_line("// then call the kernel")
     if single_call_timing:
         self.gen_add_code_line("struct timespec start, end; clock_gettime(CLOCK_MONOTONIC,&start);")
-    self.gen_add_code_lines(["hipLaunchKernelGGL((" + kern + "),block_dimms,thread_dimms,grid_lds_bytes<T>(thread_dimms, GRID_LDS_PER_SOLVE, FDSVA_SO_STAGE_PER_SOLVE, FDSVA_SO_MAX_SOLVES_PER_BLOCK),0,hd_data->d_df2," + ("hd_data->d_idsva_so," if self.gen_idsva_so_direct() else "") + "hd_data->d_q_qd_u,stride_q_qd_u,d_robotModel,gravity,num_timesteps);",
+    self.gen_add_code_lines(["hipLaunchKernelGGL((" + kern + "),block_dimms,thread_dimms,grid_lds_bytes<T>(thread_dimms, FDSVA_SO_LDS_PER_SOLVE, FDSVA_SO_STAGE_PER_SOLVE, FDSVA_SO_MAX_SOLVES_PER_BLOCK),0,hd_data->d_df2," + ("hd_data->d_idsva_so," if self.gen_idsva_so_direct() else "") + "hd_data->d_q_qd_u,stride_q_qd_u,d_robotModel,gravity,num_timesteps);",
                              "gpuErrchk(hipGetLastError()); gpuErrchk(hipDeviceSynchronize());"])
     if single_call_timing:
         self.gen_add_code_line("clock_gettime(CLOCK_MONOTONIC,&end);")
@@ -294,6 +369,8 @@ def gen_fdsva_so(self, use_thread_group=False):
         return
     self.gen_fdsva_so_inner(use_thread_group)
     self.gen_fdsva_so_device(use_thread_group)
+    if self.gen_fdsva_so_fused_layout() is not None:
+        self.gen_fdsva_so_fused_device(use_thread_group)
     self.gen_fdsva_so_kernel(use_thread_group, True)
     self.gen_fdsva_so_kernel(use_thread_group, False)
     for mode in (0, 1, 2):

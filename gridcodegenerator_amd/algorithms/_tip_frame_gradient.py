@@ -526,15 +526,20 @@ def _emit_ldl_solve(self, b, U="Uf", rd="rd"):
         self.gen_add_code_line("%s[%d] -= %s;" % (b, k, " + ".join("%s%d_%d*%s[%d]" % (U, i, k, b, i) for i in range(k))))
 
 
-def gen_forward_dynamics_gradient_inner_tip(self, use_thread_group=False, use_qdd_Minv_input=False):
+def gen_forward_dynamics_gradient_inner_tip(self, use_thread_group=False, use_qdd_Minv_input=False, with_so=False):
     """The fused inner of the tip-frame path.
+    with_so (u-input form only): forward_dynamics_gradient_inner_tip_so - what fdsva_so runs.  At the end of the gradient every per-joint quantity the
+    second-order inverse-dynamics derivatives are built from is in this lane's registers, evaluated at qdd = FD(q, qd, u): S, Pd, Pdd, the composites
+    I^C, B^C and t1..t4 (= T1, T4, T3, -T2 of algorithms/_idsva_so.py); the function goes straight on to the idsva_so main loops instead of
+    idsva_so_device deriving frames, velocities and composites a second time (the reference composes the two calls, algorithms/_fdsva_so.py:147-156).
     (qdd, Minv)-input form: frame chain, link setup, assembly of dc/du, product with the caller's M^-1.
     u-input form: additionally the joint-space inertia itself comes from the tip-frame composites, M[k][j] = S_k . (I^C_j S_j) for k <= j,
     and is never inverted: every lane factors it (U D U^T, wave-uniform registers) and solves for tau - c and for its own two columns
     of dc/du.  No link-local transforms, no articulated inertias, no M^-1 sweeps."""
     m = self.model
     n = m.n
-    name = "forward_dynamics_gradient_inner_tip" + ("_qdd_minv" if use_qdd_Minv_input else "")
+    assert not (with_so and use_qdd_Minv_input)
+    name = "forward_dynamics_gradient_inner_tip" + ("_qdd_minv" if use_qdd_Minv_input else "") + ("_so" if with_so else "")
     notes = ["serial revolute chains only; all link quantities are expressed in the frame of the tip link (see the module notes of",
              "algorithms/_tip_frame_gradient.py); same results as direct_minv_inner + inverse_dynamics_inner + inverse_dynamics_gradient_inner",
              "s_df_du receives -Minv*dc/du in the device layout [col*n + row]; the caller must grid_wave_sync() before other lanes read it"]
@@ -549,6 +554,12 @@ def gen_forward_dynamics_gradient_inner_tip(self, use_thread_group=False, use_qd
                    "s_G is LDS scratch for the per-joint hand-off records (16 values per joint)", "s_M is LDS scratch for the joint-space inertia matrix (leading dimension GRID_MINV_LD)"]
         params += ["s_qdd_out, s_Minv_out (optional, after lane): where to leave qdd = FD(q, qd, u) and the dense M^-1 (leading dimension GRID_MINV_LD; may be s_M) - what fdsva_so needs besides the gradient"]
         sig = "T *s_df_du, const T *s_qd, const T *s_u, const T *s_X, T *s_G, T *s_M, const robotModel<T> *d_robotModel, const T gravity, const int lane, T *s_qdd_out = nullptr, T *s_Minv_out = nullptr"
+        if with_so:
+            params += ["so is the idsva_so record of this solve (the compact staging record where GRID_SO_COMPACT is 1, else the dense 4*NUM_JOINTS^3 record; LDS or global memory);",
+                       "   the tensors are those of inverse dynamics at qdd = FD(q, qd, u); it may overlap s_X, s_G, s_M, s_qd and s_u (all dead by the time it is written), not s_df_du / s_Minv_out / s_rec",
+                       "active is false for lane groups without a solve (they compute but do not store through so)"]
+            params += ["s_rec is LDS for the per-joint records [S | Pd | Pdd] of the second-order loops, 20 values per joint (may be s_X)"]
+            sig = sig.replace(" = nullptr", "") + ", T *so, T *s_rec, const bool active"  # (no __restrict__: so may overlap the gradient's dead working set)
     params += ["d_robotModel is the pointer to the initialized model specific helpers on the GPU", "gravity is the gravity constant",
                "lane is the caller's lane index inside the solve's lane group"]
     self.gen_add_func_doc("Computes the gradient of forward dynamics in the tip frame", notes, params, None)
@@ -740,6 +751,36 @@ def gen_forward_dynamics_gradient_inner_tip(self, use_thread_group=False, use_qd
         self.gen_add_code_line("for (int k = 0; k < %d; k++) { s_Minv_out[lane*%d + base + k] = e[k]; }" % (L, ld))
         self.gen_add_end_control_flow()
         self.gen_add_end_control_flow()
+    if with_so:
+        from ._idsva_so import _so_emit_balanced_main_dots
+        compact = self.gen_idsva_so_compact()
+        A = self.gen_add_code_line
+        A("//")
+        A("// second-order derivatives of inverse dynamics at this qdd (algorithms/_idsva_so.py): everything they are built from is in registers")
+        A("//")
+        A("T T1[6], T2[3], T3[6], T4[6], ICPd[6];")
+        A("#pragma unroll")
+        A("for (int r = 0; r < 6; r++) { T1[r] = t1[r]; T3[r] = t3[r]; T4[r] = t2[r]; }")
+        A("T2[0] = -t4[0]; T2[1] = -t4[1]; T2[2] = -t4[2];")
+        A("grid_rbi_mul(ICPd, IC, Pd);")
+        self.gen_add_sync(use_thread_group)  # (every lane is done with X(q) and with the records of the gradient)
+        A("{ // (from here on s_X names the records of the second-order loops)", True)
+        A("T *s_X = s_rec;")
+        A("if (lane < %d) { // record of joint `lane`: [S | Pd | Pdd]" % n, True)
+        A("T *rec = &s_X[20*lane];")
+        A("#pragma unroll")
+        A("for (int r = 0; r < 6; r++) { rec[r] = S[r]; rec[6 + r] = Pd[r]; rec[12 + r] = Pdd[r]; }")
+        self.gen_add_end_control_flow()
+        if compact:
+            A("if (lane == 0) { so[%d] = static_cast<T>(0); } // the ZERO slot: what the structurally zero entries of dM_dq expand from" % self.gen_idsva_so_compact_layout()["ZERO"])
+        else:
+            A("{ // structurally zero entries of dM_dq: dM_ik/dq_j with j <= min(i, k); the owner lane (largest index) writes them first")
+            A("  T *mq = so + %d; const int c = lane;" % (3 * n ** 3))
+            A("  #pragma unroll 1")
+            A("  for (int b = 0; b < %d; b++) { for (int e = 0; e <= b; e++) { if (active && c < %d && b <= c) { mq[(c*%d + e)*%d + b] = static_cast<T>(0); mq[(b*%d + e)*%d + c] = static_cast<T>(0); } } } }" % (n, n, n, n, n, n))
+        self.gen_add_sync(use_thread_group)
+        _so_emit_balanced_main_dots(self, tree=False, compact=compact)
+        self.gen_add_end_control_flow()
     if ts_mode:
         self.gen_add_sync(use_thread_group)
         TS(6)
@@ -920,6 +961,14 @@ def gen_tip_frame_components(self, use_thread_group=False):
     self.gen_direct_minv_inner_tip(use_thread_group)
 
 
+def gen_tip_frame_fused_so(self):
+    """True where fdsva_so runs the fused inner forward_dynamics_gradient_inner_tip_so (one chain, the balanced dot-product loops, tuning so_fused)."""
+    return bool(self.tip_frame and not getattr(self, "branch_frame", False) and self.tip_nseg == 1 and self.tuning["so_fused"] and self.gen_idsva_so_mode() == "chain"
+                and self.tuning["so_mapping"] == "balanced" and self.tuning["so_loops"] == "dots" and int(self.tuning["debug_stop"]) == 0)
+
+
 def gen_tip_frame_gradient(self, use_thread_group=False):
     self.gen_forward_dynamics_gradient_inner_tip(use_thread_group, False)
     self.gen_forward_dynamics_gradient_inner_tip(use_thread_group, True)
+    if self.gen_tip_frame_fused_so():
+        self.gen_forward_dynamics_gradient_inner_tip(use_thread_group, False, with_so=True)

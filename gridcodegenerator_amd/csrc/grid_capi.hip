@@ -320,7 +320,7 @@ static int fdsva_so_device(grid_handle *h, const T *d_q_qd_u, int stride, int N,
     GRID_ON_DEVICE(h);
     if ((rc = ensure_typed<T>(h))) return rc;
     launch_cfg c;
-    if ((rc = make_launch<T>(h, N, grid_so::FDSVA_SO_SUGGESTED_THREADS, grid_so::FDSVA_SO_MAX_SOLVES_PER_BLOCK, grid_so::GRID_LDS_PER_SOLVE, grid_so::FDSVA_SO_STAGE_PER_SOLVE, &c, grid_so::GRID_LANES_PER_SOLVE))) return rc;
+    if ((rc = make_launch<T>(h, N, grid_so::FDSVA_SO_SUGGESTED_THREADS, grid_so::FDSVA_SO_MAX_SOLVES_PER_BLOCK, grid_so::FDSVA_SO_LDS_PER_SOLVE, grid_so::FDSVA_SO_STAGE_PER_SOLVE, &c, grid_so::GRID_LANES_PER_SOLVE))) return rc;
 #if GRID_SO_DIRECT
     // the idsva_so tensors of a solve do not fit LDS: the kernel keeps them in the handle's d_idsva_so buffer
     if (N > so_capacity<T>(h)) return fail_msg(hipErrorInvalidValue, "num_timesteps exceeds the handle's second-order workspace (grid_second_order_capacity)");
