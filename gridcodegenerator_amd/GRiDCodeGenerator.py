@@ -27,6 +27,12 @@ TUNING_DEFAULTS = {
     "so_mapping": "balanced",   # balanced | subtree: work distribution of the idsva_so main loops (algorithms/_idsva_so.py: gen_idsva_so_items)
     "so_loops": "dots",         # dots | mxm: loop bodies of the balanced idsva_so main loops - every cross product folded into per-item vectors, a step is dot products
                                 # only (algorithms/_idsva_so.py: _SO_FOLD), or the round-2 bodies with motion cross products per step
+    "so_origin": "joint",       # joint | base: tree form of the second-order kernels - link inertias, Coriolis matrices, forces and their subtree composites about the origin of every
+                                # joint's own frame (shifted from child to parent on the way up; the vectors of joints m, l are shifted to joint c's origin inside the items), or
+                                # everything about the base origin (round 2: entries of light distal links are then small differences of m d^2 terms - fp32 errors of 4e-7 of
+                                # max|dM_dq| became 8e-4 of max|d2a_dtdq| behind the two products with M^-1 in fdsva_so on the 12-DoF tree)
+    "so_blocked": True,         # fdsva_so of robots with several base-rooted components: the contraction runs per component (M^-1, df/du and the idsva_so tensors are block
+                                # diagonal over them: 7.5x fewer multiply-adds on the 30-DoF humanoid, 64x on the quadruped; algorithms/_fdsva_so.py: _BLOCKED)
     "so_fused": True,           # fdsva_so of serial chains: the forward-dynamics-gradient inner goes straight on to the idsva_so main loops with the per-joint quantities it holds
                                 # in registers (one pass over frames, velocities and composites instead of two; algorithms/_tip_frame_gradient.py: with_so)
     "so_stage": "auto",         # auto | compact | dense: LDS staging of the idsva_so record - compact = every value once (symmetric entries, no structural zeros), expanded
@@ -38,6 +44,8 @@ TUNING_DEFAULTS = {
                                 # half the staging per wave, twice the lanes in the item loops (7-DoF arm, 65 536 solves: idsva_so 289 -> 195 us)
     "so_direct": "auto",        # auto | True: second-order kernels write their 4 n^3 record straight to global memory instead of staging it in LDS
                                 # (auto = only where the record does not fit LDS, algorithms/_idsva_so.py: gen_idsva_so_direct)
+    "lane_interleave": True,    # 8-lane groups: the two solves of a 16-lane DPP row interleave (solve = lane parity, joint = lane / 2), so that the row's end IS
+                                # the solve's end for the lane-group scans: no masked multiply with the neighbouring solve's values (0 * NaN), no masks at all
     "dpp_asm": True,            # lane-group scans as single v_fmac_f32_dpp instructions (inline asm) instead of builtin DPP move + FMA
     "tip_chain": "select",      # select | lds: how the tip-frame chain hands (R, p) to the owning lane
     "nt_store": True,           # non-temporal output stores
@@ -87,6 +95,8 @@ def resolve_tuning(tuning=None, COLS_PER_LANE=None):
         raise ValueError("tuning['cols_per_lane'] must be 1 or 2")
     if t["tip_chain"] not in ("select", "lds"):
         raise ValueError("tuning['tip_chain'] must be select or lds")
+    if t["so_origin"] not in ("joint", "base"):
+        raise ValueError("tuning['so_origin'] must be joint or base")
     if t["so_loops"] not in ("dots", "mxm"):
         raise ValueError("tuning['so_loops'] must be dots or mxm")
     return t
@@ -113,7 +123,7 @@ class GRiDCodeGenerator:
         gen_forward_dynamics_host, gen_forward_dynamics, \
         gen_aba_inner_temp_mem_size, gen_aba_inner_function_call, gen_aba_inner, gen_aba_device, gen_aba_kernel, gen_aba_host, gen_aba, \
         gen_idsva_so_available, gen_idsva_so_mode, gen_idsva_so_direct, gen_idsva_so_compact, gen_idsva_so_compact_layout, gen_idsva_so_rec, gen_idsva_so_tree_tables, gen_idsva_so_items, gen_idsva_so_items_table, gen_idsva_so_lds_layout, gen_idsva_so_inner_temp_mem_size, gen_idsva_so_inner_function_call, gen_idsva_so_inner, gen_idsva_so_device, gen_idsva_so_kernel, gen_idsva_so_host, gen_idsva_so, \
-        gen_fdsva_so_inner_temp_mem_size, gen_fdsva_so_stage_size, gen_fdsva_so_fused_layout, gen_fdsva_so_lds_per_solve, gen_fdsva_so_fused_device, gen_fdsva_so_inner, gen_fdsva_so_device, gen_fdsva_so_kernel, gen_fdsva_so_host, gen_fdsva_so, \
+        gen_fdsva_so_inner_temp_mem_size, gen_fdsva_so_stage_size, gen_fdsva_so_fused_layout, gen_fdsva_so_components, gen_fdsva_so_lds_per_solve, gen_fdsva_so_fused_device, gen_fdsva_so_inner, gen_fdsva_so_device, gen_fdsva_so_kernel, gen_fdsva_so_host, gen_fdsva_so, \
         gen_inverse_dynamics_gradient_inner_temp_mem_size, gen_inverse_dynamics_gradient_kernel_max_temp_mem_size, \
         gen_inverse_dynamics_gradient_inner_function_call, gen_inverse_dynamics_gradient_inner, gen_dc_du_to_lds, gen_gradient_slots, gen_gradient_outputs_decl, \
         gen_inverse_dynamics_gradient_device, gen_inverse_dynamics_gradient_kernel, gen_inverse_dynamics_gradient_host, gen_inverse_dynamics_gradient, \
@@ -163,6 +173,9 @@ class GRiDCodeGenerator:
         while lanes < need:
             lanes *= 2
         self.lanes_per_solve = lanes          # lane j of a group <-> joint j; 6 lanes also carry the articulated inertia columns
+        # 8-lane groups: two solves share one 16-lane DPP row.  Interleaved (thread t of a row: solve t & 1, joint t >> 1) a DPP shift by 2k moves k joints inside ONE
+        # solve and leaves the row exactly where the solve ends; blocks are then made of whole rows (a multiple of 16 threads, GRID_MIN_THREADS)
+        self.lane_interleave = bool(lanes == 8 and self.tuning["lane_interleave"])
         # derivative-walk form (see algorithms/_inverse_dynamics_gradient.py): VGPR-resident backward sweep for shallow trees, LDS-assisted
         # forward accumulation for deep ones; and whether the gradient walk of forward_dynamics_gradient re-uses v, I v, fx(v) I v of the RNEA(qdd=0) pass
         depth_max = max(self.model.depth) + 1
@@ -268,6 +281,8 @@ class GRiDCodeGenerator:
                                  "// lane-group decomposition: GRID_LANES_PER_SOLVE consecutive lanes of one wavefront own one solve",
                                  "const int GRID_LANES_PER_SOLVE = " + str(G) + ";",
                                  "const int GRID_SOLVES_PER_WAVE = " + str(64 // G) + ";",
+                                 "const int GRID_LANE_INTERLEAVE = %d; // 1: the two solves of a 16-lane row interleave (thread t of the row: solve t & 1, joint t >> 1); blocks are whole rows" % (1 if self.lane_interleave else 0),
+                                 "const int GRID_MIN_THREADS = %d; // smallest block (and block-size granule): one %s" % ((16, "16-lane row = two solves") if self.lane_interleave else (G, "lane group")),
                                  "const int GRID_MAX_THREADS = " + str(self.max_threads) + "; // __launch_bounds__ of every kernel",
                                  "#define GRID_LAUNCH_BOUNDS __launch_bounds__(" + str(self.max_threads) + (", " + str(self.min_waves_per_eu) if self.min_waves_per_eu else "") + ")",
                                  "const int SUGGESTED_THREADS = " + str(self.suggested_threads) + ";",

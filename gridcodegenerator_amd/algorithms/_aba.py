@@ -80,7 +80,7 @@ def gen_aba_inner(self, use_thread_group=False):
         self.gen_add_code_line("{", True)
         self.gen_add_code_line("T U[6];")
         self.gen_add_code_line("#pragma unroll")
-        self.gen_add_code_line("for (int r = 0; r < 6; r++) { U[r] = __shfl(IA_%d[r], %d, GRID_LANES_PER_SOLVE); }" % (i, IA0 + s))
+        self.gen_add_code_line("for (int r = 0; r < 6; r++) { U[r] = grid_group_shfl(IA_%d[r], %d); }" % (i, IA0 + s))
         self.gen_add_code_line("const T Dinv = grid_rcp(U[%d]);" % s)
         self.gen_add_code_line("const T u = s_tau[%d]%s - pA_%d[%d];" % (i, (" - static_cast<T>(" + repr(float(damp)) + ")*qd_%d" % i) if damp != 0.0 else "", i, s))
         if keep:
@@ -103,7 +103,7 @@ def gen_aba_inner(self, use_thread_group=False):
             self.gen_add_code_line("const T yl = grid_dot6(Ia, c); // (Ia c)[cI]: Ia is symmetric, so its row cI is this lane's column")
             self.gen_add_code_line("const T ud = u*Dinv;")
             self.gen_add_code_line("#pragma unroll")
-            self.gen_add_code_line("for (int r = 0; r < 6; r++) { pa[r] = pA_%d[r] + __shfl(yl, %d + r, GRID_LANES_PER_SOLVE) + U[r]*ud; }" % (i, IA0))
+            self.gen_add_code_line("for (int r = 0; r < 6; r++) { pa[r] = pA_%d[r] + grid_group_shfl(yl, %d + r) + U[r]*ud; }" % (i, IA0))
             self.gen_add_code_line("grid_xtmul_peq(pA_%d, X, pa); grid_pin6(pA_%d);" % (p, p))
             self.gen_add_code_line("// IA_parent += X^T Ia X, one column per lane, transposed through LDS")
             self.gen_add_code_line("grid_xtmul(Tc, X, Ia);")

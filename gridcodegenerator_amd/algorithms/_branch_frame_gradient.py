@@ -290,9 +290,9 @@ def _emit_chain_scan(self, P, H, RL, bfam, kin, use_thread_group, ptr):
         A("{ // suffix scan over the lanes of the branch, step %d: (R, p) <- (R, p)[lane + %d] o (R, p)" % (k, k), True)
         A("T Ra[9], pa[3], Rn[9], pn[3];")
         A("#pragma unroll")
-        A("for (int r = 0; r < 9; r++) { Ra[r] = grid_lane_above<%d>(R[r]); }" % k)
+        A("for (int r = 0; r < 9; r++) { Ra[r] = grid_lane_above<%d>(R[r]); }" % (k * (2 if getattr(self, "lane_interleave", False) else 1)))
         A("#pragma unroll")
-        A("for (int r = 0; r < 3; r++) { pa[r] = grid_lane_above<%d>(p[r]); }" % k)
+        A("for (int r = 0; r < 3; r++) { pa[r] = grid_lane_above<%d>(p[r]); }" % (k * (2 if getattr(self, "lane_interleave", False) else 1)))
         A("const bool ok = active && (pos + %d < Lb);" % k)
         A("#pragma unroll")
         A("for (int r = 0; r < 3; r++) {", True)
@@ -321,13 +321,13 @@ def _emit_chain_scan(self, P, H, RL, bfam, kin, use_thread_group, ptr):
     A("#pragma unroll")
     A("for (int r = 0; r < 3; r++) { cp[r] = p[r] - (cR[3*r]*ro_[0] + cR[3*r + 1]*ro_[1] + cR[3*r + 2]*ro_[2]); }")
     A("#pragma unroll")
-    A("for (int r = 0; r < 9; r++) { TR[r] = __shfl(cR[r], l0, GRID_LANES_PER_SOLVE); }")
+    A("for (int r = 0; r < 9; r++) { TR[r] = grid_group_shfl(cR[r], l0); }")
     A("#pragma unroll")
-    A("for (int r = 0; r < 3; r++) { Tp[r] = __shfl(cp[r], l0, GRID_LANES_PER_SOLVE); }")
+    A("for (int r = 0; r < 3; r++) { Tp[r] = grid_group_shfl(cp[r], l0); }")
     self.gen_add_end_control_flow()
     if bfam:
         A("{ const int lB = (active && iB >= 0) ? l0 + Lb - 1 - iB : lane; // the lane of the branch's middle joint")
-        A("  pB[0] = __shfl(myp[0], lB, GRID_LANES_PER_SOLVE); pB[1] = __shfl(myp[1], lB, GRID_LANES_PER_SOLVE); pB[2] = __shfl(myp[2], lB, GRID_LANES_PER_SOLVE);")
+        A("  pB[0] = grid_group_shfl(myp[0], lB); pB[1] = grid_group_shfl(myp[1], lB); pB[2] = grid_group_shfl(myp[2], lB);")
         A("  if (!(active && iB >= 0)) { pB[0] = pB[1] = pB[2] = Z; } }")
     A("T *s_Gh = %s; // branch records: free until the composites are handed over (here: gravity direction per branch)" % ptr("G"))
     A("(void)s_Gh; (void)pslot;")

@@ -88,7 +88,7 @@ def gen_direct_minv_inner_body(self, use_thread_group=False, bwd_hook=None, fwd_
         self.gen_add_code_line("// U = IA[:, S] lives in the lane that owns that column: broadcast it inside the lane group (no LDS hand-off, no sync)")
         self.gen_add_code_line("T U[6];")
         self.gen_add_code_line("#pragma unroll")
-        self.gen_add_code_line("for (int r = 0; r < 6; r++) { U[r] = __shfl(IA_%d[r], %d, GRID_LANES_PER_SOLVE); }" % (i, IA0 + s))
+        self.gen_add_code_line("for (int r = 0; r < 6; r++) { U[r] = grid_group_shfl(IA_%d[r], %d); }" % (i, IA0 + s))
         self.gen_add_code_line("const T Dinv = grid_rcp(U[%d]);" % s)
         if keep_U_in_regs:
             self.gen_add_code_line("#pragma unroll")

@@ -233,7 +233,7 @@ def _so_emit_balanced_main(self, tree):
         A("T IC[10], BC[12], T1[6], T2[3], T3[6], T4[6], ICPd[6], S[6], Pd[6]; // joint c's quantities, fetched from its lane")
         for nm, ln_ in (("IC", 10), ("BC", 12), ("T1", 6), ("T2", 3), ("T3", 6), ("T4", 6), ("ICPd", 6), ("S", 6), ("Pd", 6)):
             A("#pragma unroll")
-            A("for (int r = 0; r < %d; r++) { %s[r] = __shfl(o%s[r], c, GRID_LANES_PER_SOLVE); }" % (ln_, nm, nm))
+            A("for (int r = 0; r < %d; r++) { %s[r] = grid_group_shfl(o%s[r], c); }" % (ln_, nm, nm))
         _so_emit(self, _SO_OPERATORS)
         def fetch(dst_s, dst_p, dst_par, lv, decl):
             A("%s#pragma unroll" % "")
@@ -322,7 +322,7 @@ class _SoStores:
         return "so[%d + ((%s)*%d + (%s))*%d + (%s)] = so[%d + ((%s)*%d + (%s))*%d + (%s)] = %s;" % (3 * n ** 3, i, n, j, n, k, 3 * n ** 3, k, n, j, n, i, val)
 
 
-def _so_emit_balanced_main_dots(self, tree, compact):
+def _so_emit_balanced_main_dots(self, tree, compact, local=False):
     """Main loops, balanced mapping (gen_idsva_so_items), dot-product form (see _SO_FOLD); expects the per-lane quantities of _SO_PREP (lane <-> joint) and
     the records [S | Pd | Pdd | parent] in s_X.  Writes through `so`: the dense record (LDS or global memory) or the compact staging record."""
     n, G = self.model.n, self.lanes_per_solve
@@ -343,8 +343,18 @@ def _so_emit_balanced_main_dots(self, tree, compact):
         A("T IC[10], BC[12], T1[6], T2[3], T3[6], T4[6], ICPd[6], S[6], Pd[6]; // joint c's quantities, fetched from its lane")
         for nm, ln_ in (("IC", 10), ("BC", 12), ("T1", 6), ("T2", 3), ("T3", 6), ("T4", 6), ("ICPd", 6), ("S", 6), ("Pd", 6)):
             A("#pragma unroll")
-            A("for (int r = 0; r < %d; r++) { %s[r] = __shfl(o%s[r], c, GRID_LANES_PER_SOLVE); }" % (ln_, nm, nm))
-        _so_emit(self, _SO_OPERATORS)
+            A("for (int r = 0; r < %d; r++) { %s[r] = grid_group_shfl(o%s[r], c); }" % (ln_, nm, nm))
+        if local:
+            # records hold every joint's vectors about its OWN origin ([axis | origin | Pd | Pdd]): moved to joint c's origin before they meet its composites
+            A("T pc[3] = {s_X[20*c + 3], s_X[20*c + 4], s_X[20*c + 5]}; // origin of joint c's frame: the reference point of this item")
+            _so_emit(self, _SO_OPERATORS.replace("""    T yS[6], yP[6], yPP[6];
+    #pragma unroll
+    for (int r = 0; r < 6; r++) { yS[r] = s_X[20*m + r]; yP[r] = s_X[20*m + 6 + r]; yPP[r] = s_X[20*m + 12 + r]; }""",
+                                                 """    T yS[6], yP[6], yPP[6];
+    { const T *ry = &s_X[20*m]; const T qm[3] = {pc[0] - ry[3], pc[1] - ry[4], pc[2] - ry[5]};
+      grid_so_axis_at(yS, ry, qm); grid_so_motion_at(yP, ry + 6, qm); grid_so_motion_at(yPP, ry + 12, qm); }"""))
+        else:
+            _so_emit(self, _SO_OPERATORS)
         _so_emit(self, _SO_FOLD)
 
         def fetch(dst_s, dst_p, dst_par, lv, decl):
@@ -352,17 +362,25 @@ def _so_emit_balanced_main_dots(self, tree, compact):
             A("for (int r = 0; r < 6; r++) { %s[r] = s_X[20*%s + r]; %s[r] = s_X[20*%s + 6 + r]; }" % (dst_s, lv, dst_p, lv))
             A("%s%s = %s;" % ("const int " if decl else "", dst_par, par(lv)))
 
+        def xvec():  # the step's vectors S_l, Pd_l from the fetched record words
+            if local:
+                A("T xS[6], xP[6];")
+                A("{ const T ql[3] = {pc[0] - rS[3], pc[1] - rS[4], pc[2] - rS[5]}; grid_so_axis_at(xS, rS, ql); grid_so_motion_at(xP, rP, ql); }")
+            else:
+                A("const T (&xS)[6] = rS; const T (&xP)[6] = rP;")
+
         A("if (own && c != m) { %s } // dM_dq[m][c][m]: the step l = m of the ancestor loop" % st.mq("m", "c", "m", "tm", "y_d1S"))
         # ---- path loop: joint j = l walks c -> m, ancestor-or-self an = m
         A("{ // joint j = l walks the path c -> m, ancestor-or-self an = m; the record of the next joint is fetched while this one is worked on", True)
         A("int l = c, lpar; bool va = true;")
-        A("T xS[6], xP[6];")
-        fetch("xS", "xP", "lpar", "l", False)
+        A("T rS[6], rP[6];")
+        fetch("rS", "rP", "lpar", "l", False)
         A("#pragma unroll 1")
         A("for (int t = 0; t < %d; t++) {" % tA[sl], True)
         A("const bool more = va && (l != m); const int ln = more ? lpar : l;")
         A("T nS[6], nP[6];")
         fetch("nS", "nP", "npar", "ln", True)
+        xvec()
         A("const T s_d3P = grid_dot6(xS, d3P), s_d3S = grid_dot6(xS, d3S), s_eW = grid_dot6(xS, eW), s_eV = grid_dot6(xS, eV);")
         A("const T vq_ = grid_dot6(xS, gA) - grid_dot6(xP, d3P);")
         A("const int j = l, an = m, tj = %s; (void)tj;" % tri("l"))
@@ -380,20 +398,21 @@ def _so_emit_balanced_main_dots(self, tree, compact):
         self.gen_add_end_control_flow()
         A("l = ln; va = more; lpar = npar;")
         A("#pragma unroll")
-        A("for (int r = 0; r < 6; r++) { xS[r] = nS[r]; xP[r] = nP[r]; }")
+        A("for (int r = 0; r < 6; r++) { rS[r] = nS[r]; rP[r] = nP[r]; }")
         self.gen_add_end_control_flow()
         self.gen_add_end_control_flow()
         # ---- ancestor loop: joint j = m, proper ancestor an = l walks parent(m) -> root
         if tB[sl] > 0:
             A("{ // joint j = m, proper ancestor an = l walks parent(m) -> root", True)
             A("int l = %s, lpar; bool va = l >= 0; if (!va) { l = 0; }" % par("m"))
-            A("T xS[6], xP[6];")
-            fetch("xS", "xP", "lpar", "l", False)
+            A("T rS[6], rP[6];")
+            fetch("rS", "rP", "lpar", "l", False)
             A("#pragma unroll 1")
             A("for (int t = 0; t < %d; t++) {" % tB[sl], True)
             A("const bool more = va && (lpar >= 0); const int ln = more ? lpar : l;")
             A("T nS[6], nP[6];")
             fetch("nS", "nP", "npar", "ln", True)
+            xvec()
             A("const T s_d1S = grid_dot6(xS, d1S), s_d3S = grid_dot6(xS, d3S), s_d4S = grid_dot6(xS, d4S), s_eV = grid_dot6(xS, eV), s_e3 = grid_dot6(xS, e3), s_e4 = grid_dot6(xS, e4);")
             A("const T vq_ = grid_dot6(xS, gC) + static_cast<T>(2)*grid_dot6(xP, d4S);")
             A("const int j = m, an = l;")
@@ -411,7 +430,7 @@ def _so_emit_balanced_main_dots(self, tree, compact):
             self.gen_add_end_control_flow()
             A("l = ln; va = more; lpar = npar;")
             A("#pragma unroll")
-            A("for (int r = 0; r < 6; r++) { xS[r] = nS[r]; xP[r] = nP[r]; }")
+            A("for (int r = 0; r < 6; r++) { rS[r] = nS[r]; rP[r] = nP[r]; }")
             self.gen_add_end_control_flow()
             self.gen_add_end_control_flow()
         self.gen_add_end_control_flow()
@@ -625,6 +644,61 @@ for (int m = 0; m < @N@; m++) {""")
     self.gen_add_end_function()
 
 
+_SO_SHIFT_LIBRARY = """
+// --- change of reference point (same axes): q = position of the NEW origin relative to the old one -------------------------------------
+// motion vector [w; u] (u = velocity of the point at the origin): u' = u + w x q
+template <typename T>
+__device__ __forceinline__ void grid_so_motion_at(T (&y)[6], const T *x, const T (&q)[3]) {
+    y[0] = x[0]; y[1] = x[1]; y[2] = x[2];
+    y[3] = x[3] + x[1]*q[2] - x[2]*q[1]; y[4] = x[4] + x[2]*q[0] - x[0]*q[2]; y[5] = x[5] + x[0]*q[1] - x[1]*q[0];
+}
+// joint axis through the old origin (linear part zero there): [w; w x q]
+template <typename T>
+__device__ __forceinline__ void grid_so_axis_at(T (&y)[6], const T *w, const T (&q)[3]) {
+    y[0] = w[0]; y[1] = w[1]; y[2] = w[2];
+    y[3] = w[1]*q[2] - w[2]*q[1]; y[4] = w[2]*q[0] - w[0]*q[2]; y[5] = w[0]*q[1] - w[1]*q[0];
+}
+// y += [I^C (10) | B^C (12) | f^C (6)] of a subtree, moved to the new reference point (rigid-body inertia: h' = h - m q, parallel axes;
+// Coriolis matrix [Sym | n | l]: Sym' = Sym + l q^T + q l^T - 2 (q.l) 1, n' = n - q x l; force [n; f]: n' = n - q x f)
+template <typename T>
+__device__ __forceinline__ void grid_so_composite_peq(T (&IC)[10], T (&BC)[12], T (&fC)[6], const T *rec, const T (&q)[3]) {
+    {
+        const T *I = rec; const T m = I[9];
+        const T s = static_cast<T>(-2)*(I[6]*q[0] + I[7]*q[1] + I[8]*q[2]) + m*(q[0]*q[0] + q[1]*q[1] + q[2]*q[2]);
+        IC[0] += I[0] + s + static_cast<T>(2)*I[6]*q[0] - m*q[0]*q[0];
+        IC[1] += I[1] + I[6]*q[1] + q[0]*I[7] - m*q[0]*q[1];
+        IC[2] += I[2] + I[6]*q[2] + q[0]*I[8] - m*q[0]*q[2];
+        IC[3] += I[3] + s + static_cast<T>(2)*I[7]*q[1] - m*q[1]*q[1];
+        IC[4] += I[4] + I[7]*q[2] + q[1]*I[8] - m*q[1]*q[2];
+        IC[5] += I[5] + s + static_cast<T>(2)*I[8]*q[2] - m*q[2]*q[2];
+        IC[6] += I[6] - m*q[0]; IC[7] += I[7] - m*q[1]; IC[8] += I[8] - m*q[2]; IC[9] += m;
+    }
+    {
+        const T *B = rec + 10; const T l0 = B[9], l1 = B[10], l2 = B[11];
+        const T s = static_cast<T>(-2)*(q[0]*l0 + q[1]*l1 + q[2]*l2);
+        BC[0] += B[0] + s + static_cast<T>(2)*l0*q[0];
+        BC[1] += B[1] + l0*q[1] + q[0]*l1;
+        BC[2] += B[2] + l0*q[2] + q[0]*l2;
+        BC[3] += B[3] + s + static_cast<T>(2)*l1*q[1];
+        BC[4] += B[4] + l1*q[2] + q[1]*l2;
+        BC[5] += B[5] + s + static_cast<T>(2)*l2*q[2];
+        BC[6] += B[6] - (q[1]*l2 - q[2]*l1); BC[7] += B[7] - (q[2]*l0 - q[0]*l2); BC[8] += B[8] - (q[0]*l1 - q[1]*l0);
+        BC[9] += l0; BC[10] += l1; BC[11] += l2;
+    }
+    {
+        const T *f = rec + 22;
+        fC[0] += f[0] - (q[1]*f[5] - q[2]*f[4]); fC[1] += f[1] - (q[2]*f[3] - q[0]*f[5]); fC[2] += f[2] - (q[0]*f[4] - q[1]*f[3]);
+        fC[3] += f[3]; fC[4] += f[4]; fC[5] += f[5];
+    }
+}
+"""
+
+
+def gen_idsva_so_local_origin(self):
+    """True where the tree form keeps every joint's quantities about the origin of its own frame (tuning so_origin)."""
+    return self.gen_idsva_so_mode() == "tree" and self.tuning["so_origin"] == "joint" and self.tuning["so_mapping"] == "balanced" and self.tuning["so_loops"] == "dots"
+
+
 def gen_idsva_so_inner_tree(self, use_thread_group=False):
     """Tree form.  Same operators and the same merged per-entry formulas as the chain form; what changes is where the per-joint quantities come from
     (level-by-level propagation through LDS instead of lane scans, all in the base frame) and which (m, l) pairs are visited: the reference's triples
@@ -635,6 +709,12 @@ def gen_idsva_so_inner_tree(self, use_thread_group=False):
     fl, it, K, maxc = self.gen_idsva_so_tree_tables()
     depth = max(m_.depth)
     off = self.so_tree_tab_offset
+    local = gen_idsva_so_local_origin(self)
+    if local and not getattr(self, "_so_shift_lib_done", False):
+        for line in _SO_SHIFT_LIBRARY.strip("\n").split("\n"):
+            self.gen_add_code_line(line)
+        self.gen_add_code_line("")
+        self._so_shift_lib_done = True
     _so_inner_header(self)
     A = self.gen_add_code_line
     A("const int *tp = &grid_so_tree_topology[%d*lane]; // this lane's row: parent, level, subtree size, number of children, children" % K)
@@ -653,7 +733,7 @@ def gen_idsva_so_inner_tree(self, use_thread_group=False):
     A("if (active) { for (int e = lane; e < %d; e += GRID_LANES_PER_SOLVE) { so[e] = static_cast<T>(0); } }" % (4 * n ** 3))
     A("// top-down, one tree level at a time: pose of the link frame in the base frame (myR: link -> base coordinates, myp: its origin), joint axis S,")
     A("// spatial velocity v, acceleration a (with the gravity term) and Pd = v_parent x S; a joint's record [myR | myp | v | a] waits in LDS for its children")
-    A("T myR[9], myp[3], S[6], v[6], a[6], Pd[6];")
+    A("T myR[9], myp[3], S[6], v[6], a[6], Pd[6], dpar[3] = {static_cast<T>(0), static_cast<T>(0), static_cast<T>(0)}; // (dpar: origin of this joint's frame relative to its parent's, base axes)")
     A("#pragma unroll")
     A("for (int r = 0; r < 6; r++) { S[r] = v[r] = a[r] = Pd[r] = static_cast<T>(0); }")
     A("#pragma unroll")
@@ -680,7 +760,7 @@ def gen_idsva_so_inner_tree(self, use_thread_group=False):
     A("for (int r = 0; r < 3; r++) { // myR = Rp E^T, myp = pp + Rp r_joint", True)
     A("#pragma unroll")
     A("for (int cc = 0; cc < 3; cc++) { myR[3*r + cc] = Rp[3*r]*E[3*cc] + Rp[3*r+1]*E[3*cc+1] + Rp[3*r+2]*E[3*cc+2]; }")
-    A("myp[r] = pp[r] + Rp[3*r]*Lc[12] + Rp[3*r+1]*Lc[13] + Rp[3*r+2]*Lc[14];")
+    A("dpar[r] = Rp[3*r]*Lc[12] + Rp[3*r+1]*Lc[13] + Rp[3*r+2]*Lc[14]; myp[r] = pp[r] + dpar[r];")
     self.gen_add_end_control_flow()
     A("{ const int ax = static_cast<int>(Lc[11]);")
     A("  #pragma unroll")
@@ -699,17 +779,24 @@ def gen_idsva_so_inner_tree(self, use_thread_group=False):
     self.gen_add_end_control_flow()
     self.gen_add_sync(use_thread_group)
     self.gen_add_end_control_flow()
-    _emit_link_inertia(self)
+    if local:
+        A("// from here on every quantity of this joint is taken about the ORIGIN OF ITS OWN FRAME (base axes): the joint axis passes through it, the link's inertia, Coriolis")
+        A("// matrix and force and their subtree composites are those of a body next to the reference point - about the base origin the entries of light distal links")
+        A("// are small differences of m d^2 terms, and fdsva_so multiplies them by M^-1 twice (fp32: 4e-7 of max|dM_dq| became 8e-4 of max|d2a_dtdq| on the 12-DoF tree)")
+        A("S[3] = S[4] = S[5] = static_cast<T>(0);")
+        A("{ T t[6]; grid_so_motion_at(t, v, myp); v[3] = t[3]; v[4] = t[4]; v[5] = t[5]; grid_so_motion_at(t, a, myp); a[3] = t[3]; a[4] = t[4]; a[5] = t[5]; }")
+        A("grid_mxm(Pd, v, S);")
+    _emit_link_inertia(self, local_origin=local)
     _emit_body_terms(self)
     A("#pragma unroll")
     A("for (int r = 0; r < 10; r++) { IC[r] = has ? I[r] : static_cast<T>(0); }")
-    A("// bottom-up, one tree level at a time: composites over the subtree, [I^C | B^C | f^C] of a joint waits in LDS for its parent")
+    A("// bottom-up, one tree level at a time: composites over the subtree, [I^C | B^C | f^C] of a joint waits in LDS for its parent" + (" (about the joint's own origin; the parent moves it to its own)" if local else ""))
     A("#pragma unroll 1")
     A("for (int L = %d; L >= 0; L--) {" % depth, True)
     A("if (has && lev == L) {", True)
     A("#pragma unroll 1")
     A("for (int ci = 0; ci < tp[3]; ci++) {", True)
-    A("const T *rec = &s_X[28*tp[4 + ci]];")
+    A("const T *rec = &s_X[28*tp[4 + ci]]; // (local origins: the child has moved its composite to THIS joint's origin)")
     A("#pragma unroll")
     A("for (int r = 0; r < 10; r++) { IC[r] += rec[r]; }")
     A("#pragma unroll")
@@ -718,19 +805,38 @@ def gen_idsva_so_inner_tree(self, use_thread_group=False):
     A("for (int r = 0; r < 6; r++) { fC[r] += rec[22 + r]; }")
     self.gen_add_end_control_flow()
     A("T *out = &s_X[28*lane];")
-    A("#pragma unroll")
-    A("for (int r = 0; r < 10; r++) { out[r] = IC[r]; }")
-    A("#pragma unroll")
-    A("for (int r = 0; r < 12; r++) { out[10 + r] = BC[r]; }")
-    A("#pragma unroll")
-    A("for (int r = 0; r < 6; r++) { out[22 + r] = fC[r]; }")
+    if local:
+        A("{ // what the parent adds: this subtree's composite about the PARENT's origin (-dpar from here)", True)
+        A("T own[28], Iu[10], Bu[12], fu[6]; const T q[3] = {-dpar[0], -dpar[1], -dpar[2]};")
+        A("#pragma unroll")
+        A("for (int r = 0; r < 10; r++) { own[r] = IC[r]; Iu[r] = static_cast<T>(0); }")
+        A("#pragma unroll")
+        A("for (int r = 0; r < 12; r++) { own[10 + r] = BC[r]; Bu[r] = static_cast<T>(0); }")
+        A("#pragma unroll")
+        A("for (int r = 0; r < 6; r++) { own[22 + r] = fC[r]; fu[r] = static_cast<T>(0); }")
+        A("grid_so_composite_peq(Iu, Bu, fu, own, q);")
+        A("#pragma unroll")
+        A("for (int r = 0; r < 10; r++) { out[r] = Iu[r]; }")
+        A("#pragma unroll")
+        A("for (int r = 0; r < 12; r++) { out[10 + r] = Bu[r]; }")
+        A("#pragma unroll")
+        A("for (int r = 0; r < 6; r++) { out[22 + r] = fu[r]; }")
+        self.gen_add_end_control_flow()
+    else:
+        A("#pragma unroll")
+        A("for (int r = 0; r < 10; r++) { out[r] = IC[r]; }")
+        A("#pragma unroll")
+        A("for (int r = 0; r < 12; r++) { out[10 + r] = BC[r]; }")
+        A("#pragma unroll")
+        A("for (int r = 0; r < 6; r++) { out[22 + r] = fC[r]; }")
     self.gen_add_end_control_flow()
     self.gen_add_sync(use_thread_group)
     self.gen_add_end_control_flow()
-    _so_emit(self, _SO_PREP, PARENT="rec[18] = static_cast<T>(par); // parent joint id (-1: base), read by the balanced main loops")
+    _so_emit(self, _SO_PREP, PARENT="rec[18] = static_cast<T>(par); // parent joint id (-1: base), read by the balanced main loops" +
+             ("\n    rec[3] = myp[0]; rec[4] = myp[1]; rec[5] = myp[2]; // (the linear part of S is zero about the joint's own origin: its slots carry the origin)" if local else ""))
     if self.tuning["so_mapping"] == "balanced":
         if self.tuning["so_loops"] == "dots":
-            _so_emit_balanced_main_dots(self, tree=True, compact=False)
+            _so_emit_balanced_main_dots(self, tree=True, compact=False, local=local)
         else:
             _so_emit_balanced_main(self, tree=True)
         self.gen_add_end_function()

@@ -157,9 +157,14 @@ def gen_tip_frame_library(self):
     L = self.tip_L
     steps = [k for k in (1, 2, 4, 8) if k < L]
     ns = max(1, len(steps))
+    # interleaved 8-lane groups holding ONE chain: the lanes of a solve are every other lane of a 16-lane DPP row, joint j's neighbours are 2 lanes away and
+    # the row ends where the chain ends - a row shift with bound_ctrl reads 0 beyond it, so the steps need no masks and a lane never sees the other solve's
+    # values (a masked multiply would turn that solve's NaN / Inf into a NaN here: 0 * NaN).  Lanes without a joint hold exact zeros (zero link constants).
+    stride = 2 if getattr(self, "lane_interleave", False) else 1
+    unmasked = stride == 2 and self.tip_nseg == 1 and not getattr(self, "branch_frame", False)
     self.gen_add_code_line("")
     self.gen_add_code_line("// inclusive sums over the lanes of one chain (lane j <-> joint j; pos = position of the joint in its chain of %d): prefix = over joint j" % L)
-    self.gen_add_code_line("// and its ancestors, suffix = over joint j and its descendants.  Log-step DPP scans; mk[s] is 1 where the partner lane of step s is in the same chain.")
+    self.gen_add_code_line("// and its ancestors, suffix = over joint j and its descendants.  Log-step DPP scans" + ("; the lanes of a solve are every other lane of a 16-lane row, which ends where the chain ends: no masks" if unmasked else "; mk[s] is 1 where the partner lane of step s is in the same chain."))
     self.gen_add_code_line("#define GRID_SCAN_STEPS %d" % ns)
     for name, fn, cmp_ in (("prefix", "grid_lane_below", "pos >= %d"), ("suffix", "grid_lane_above", "pos + %d < %d")):
         self.gen_add_code_line("template <typename T>")
@@ -172,11 +177,14 @@ def gen_tip_frame_library(self):
         self.gen_add_end_function()
         self.gen_add_code_line("template <int N, typename T>")
         self.gen_add_code_line("__device__ __forceinline__ void grid_%s_sum(T (&x)[N], const T (&mk)[GRID_SCAN_STEPS]) {" % name, True)
-        if not steps:
+        if not steps or unmasked:
             self.gen_add_code_line("(void)x; (void)mk;")
         for s_, k in enumerate(steps):
             self.gen_add_code_line("#pragma unroll")
-            self.gen_add_code_line("for (int r = 0; r < N; r++) { x[r] += mk[%d]*%s<%d>(x[r]); }" % (s_, fn, k))
+            if unmasked:
+                self.gen_add_code_line("for (int r = 0; r < N; r++) { x[r] += %s<%d>(x[r]); }" % (fn, k * stride))
+            else:
+                self.gen_add_code_line("for (int r = 0; r < N; r++) { x[r] += mk[%d]*%s<%d>(x[r]); }" % (s_, fn, k * stride))
         self.gen_add_end_function()
     if self.tuning["dpp_asm"]:
         # fp32 device code: one v_fmac_f32_dpp per value and step instead of the v_mov_b32_dpp + v_fma pair the compiler emits for the
@@ -188,12 +196,18 @@ def gen_tip_frame_library(self):
                 self.gen_add_code_line("__device__ __forceinline__ void grid_%s_sum(float (&x)[%d], const float (&mk)[GRID_SCAN_STEPS]) {" % (name, N), True)
                 if not steps:
                     self.gen_add_code_line("(void)x; (void)mk;")
+                if unmasked:
+                    self.gen_add_code_line("(void)mk;")
                 for s_, k in enumerate(steps):
                     for lo in range(0, N, 6):
                         cnt = min(6, N - lo)
-                        body = "s_nop 1" + "".join("\\n\\tv_fmac_f32_dpp %%%d, %%%d, %%%d %s:%d row_mask:0xf bank_mask:0xf bound_ctrl:1" % (r, r, cnt, ctrl, k) for r in range(cnt))
                         outs = ", ".join('"+v"(x[%d])' % (lo + r) for r in range(cnt))
-                        self.gen_add_code_line('asm("%s" : %s : "v"(mk[%d]));' % (body, outs, s_))
+                        if unmasked:  # x += (the value 2k lanes away, 0 beyond the row): one v_add_f32_dpp
+                            body = "s_nop 1" + "".join("\\n\\tv_add_f32_dpp %%%d, %%%d, %%%d %s:%d row_mask:0xf bank_mask:0xf bound_ctrl:1" % (r, r, r, ctrl, k * stride) for r in range(cnt))
+                            self.gen_add_code_line('asm("%s" : %s);' % (body, outs))
+                        else:
+                            body = "s_nop 1" + "".join("\\n\\tv_fmac_f32_dpp %%%d, %%%d, %%%d %s:%d row_mask:0xf bank_mask:0xf bound_ctrl:1" % (r, r, cnt, ctrl, k * stride) for r in range(cnt))
+                            self.gen_add_code_line('asm("%s" : %s : "v"(mk[%d]));' % (body, outs, s_))
                 self.gen_add_end_function()
         self.gen_add_code_line("#endif")
     self.gen_add_code_line("")
@@ -303,16 +317,17 @@ def _emit_link_setup(self, kinematics=True, base_family=False):
     self.gen_add_code_line("T Pd[6]; grid_mxm(Pd, v, S); // = S_j-dot")
 
 
-def _emit_link_inertia(self, base_family=False):
-    """I[10]: the lane's link inertia about the origin of the working frame, from (myR, myp) and the link constants Lc."""
-    self.gen_add_code_line("T I[10]; // this link's inertia about the origin of F")
+def _emit_link_inertia(self, base_family=False, local_origin=False):
+    """I[10]: the lane's link inertia about the origin of the working frame, from (myR, myp) and the link constants Lc
+    (local_origin: about the origin of the link's own joint frame, in F's axes - the tree form of the second-order kernels)."""
+    self.gen_add_code_line("T I[10]; // this link's inertia about the origin of " + ("its own joint frame (axes of F)" if local_origin else "F"))
     if base_family and self.tip_jB is not None:
         self.gen_add_code_line("T IB[10], SB[3]; // ... and about pB, and the linear part of S about pB (base family, see _emit_base_family)")
     self.gen_add_code_line("{", True)
     self.gen_add_code_line("T d[3], RI[9], rot[6];")
     self.gen_add_code_line("#pragma unroll")
     self.gen_add_code_line("for (int r = 0; r < 3; r++) {", True)
-    self.gen_add_code_line("d[r] = myp[r] + myR[3*r]*Lc[6] + myR[3*r+1]*Lc[7] + myR[3*r+2]*Lc[8]; // centre of mass")
+    self.gen_add_code_line("d[r] = %smyR[3*r]*Lc[6] + myR[3*r+1]*Lc[7] + myR[3*r+2]*Lc[8]; // centre of mass" % ("" if local_origin else "myp[r] + "))
     self.gen_add_code_line("RI[3*r]   = myR[3*r]*Lc[0] + myR[3*r+1]*Lc[1] + myR[3*r+2]*Lc[2];")
     self.gen_add_code_line("RI[3*r+1] = myR[3*r]*Lc[1] + myR[3*r+1]*Lc[3] + myR[3*r+2]*Lc[4];")
     self.gen_add_code_line("RI[3*r+2] = myR[3*r]*Lc[2] + myR[3*r+1]*Lc[4] + myR[3*r+2]*Lc[5];")

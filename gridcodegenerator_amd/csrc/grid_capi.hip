@@ -113,8 +113,9 @@ static int make_launch(const grid_handle *h, int num_timesteps, int default_thre
                        int lanes = grid::GRID_LANES_PER_SOLVE) {
     int threads = h->threads > 0 ? h->threads : default_threads;
     if (threads < lanes) threads = lanes;  // (the second-order kernels of 8-lane robots run 16-lane groups: namespace wide)
-    if (threads < grid::GRID_LANES_PER_SOLVE || threads > grid::GRID_MAX_THREADS)
+    if (threads < grid::GRID_MIN_THREADS || threads > grid::GRID_MAX_THREADS)
         return fail_msg(hipErrorInvalidConfiguration, "threads per block out of range");
+    if (lanes == grid::GRID_LANES_PER_SOLVE) threads -= threads % grid::GRID_MIN_THREADS;  // (GRID_LANE_INTERLEAVE: blocks are whole 16-lane rows; the kernels retire the rest)
     int gpb = threads / lanes;
     if (gpb > max_groups) gpb = max_groups;  // (the kernels retire the lane groups beyond their cap)
     const size_t per_group = (size_t)(lds_per_solve + out_per_solve) * sizeof(T);
@@ -139,8 +140,8 @@ static int general_launch(const grid_handle *h, int num_timesteps, launch_cfg *c
 static int check_args(const grid_handle *h, int num_timesteps) {
     if (!h) return fail_msg(hipErrorInvalidValue, "null handle");
     if (num_timesteps < 0) return fail_msg(hipErrorInvalidValue, "negative num_timesteps");
-    if (h->threads != 0 && (h->threads < grid::GRID_LANES_PER_SOLVE || h->threads > grid::GRID_MAX_THREADS)) {
-        snprintf(g_err, sizeof(g_err), "threads per block must be in [%d, %d]", grid::GRID_LANES_PER_SOLVE, grid::GRID_MAX_THREADS);
+    if (h->threads != 0 && (h->threads < grid::GRID_MIN_THREADS || h->threads > grid::GRID_MAX_THREADS)) {
+        snprintf(g_err, sizeof(g_err), "threads per block must be in [%d, %d]", grid::GRID_MIN_THREADS, grid::GRID_MAX_THREADS);
         return (int)hipErrorInvalidConfiguration;
     }
     return 0;
@@ -564,8 +565,8 @@ int grid_device(const grid_handle *h) { return h ? h->device : -1; }
 
 int grid_set_launch_dims(grid_handle *h, int blocks, int threads) {
     if (!h) return (int)hipErrorInvalidValue;
-    if (blocks < 0 || (threads != 0 && (threads < grid::GRID_LANES_PER_SOLVE || threads > grid::GRID_MAX_THREADS))) {
-        snprintf(g_err, sizeof(g_err), "threads per block must be 0 or in [%d, %d], blocks >= 0", grid::GRID_LANES_PER_SOLVE, grid::GRID_MAX_THREADS);
+    if (blocks < 0 || (threads != 0 && (threads < grid::GRID_MIN_THREADS || threads > grid::GRID_MAX_THREADS))) {
+        snprintf(g_err, sizeof(g_err), "threads per block must be 0 or in [%d, %d] (whole lane groups; robots with 8-lane groups: whole 16-lane rows), blocks >= 0", grid::GRID_MIN_THREADS, grid::GRID_MAX_THREADS);
         return (int)hipErrorInvalidConfiguration;
     }
     h->blocks = blocks;

@@ -144,11 +144,18 @@ def gen_kernel_prologue(self, lds_per_solve_const, max_groups_const="GRID_MAX_SO
     """Lane-group decomposition shared by every kernel.  Threads beyond the last whole lane group (or beyond
     max_groups_const groups, which is what the kernel's *_DYNAMIC_SHARED_MEM_COUNT constant is sized for) retire, so a launch
     with more threads than the kernel's suggested block size stays inside the LDS the host wrappers allocate."""
-    self.gen_add_code_lines([
-        "const int tid = threadIdx.x + threadIdx.y*blockDim.x;",
-        "const int lane_id = tid & (GRID_LANES_PER_SOLVE-1); // lane j of a solve's lane group owns joint j",
-        "const int grp = tid / GRID_LANES_PER_SOLVE;",
-        "int gpb = (blockDim.x*blockDim.y) / GRID_LANES_PER_SOLVE; if (gpb > " + max_groups_const + ") {gpb = " + max_groups_const + ";}",
+    if getattr(self, "lane_interleave", False):
+        head = ["const int tid = threadIdx.x + threadIdx.y*blockDim.x;",
+                "// (GRID_LANE_INTERLEAVE) the two solves of a 16-lane row interleave: a DPP row shift by 2k moves k joints inside one solve and never reaches the other one",
+                "const int lane_id = (tid & 15) >> 1; // lane j of a solve's lane group owns joint j",
+                "const int grp = ((tid >> 4) << 1) | (tid & 1);",
+                "int gpb = ((blockDim.x*blockDim.y) >> 4) << 1; if (gpb > " + max_groups_const + ") {gpb = " + max_groups_const + ";} // (whole rows only)"]
+    else:
+        head = ["const int tid = threadIdx.x + threadIdx.y*blockDim.x;",
+                "const int lane_id = tid & (GRID_LANES_PER_SOLVE-1); // lane j of a solve's lane group owns joint j",
+                "const int grp = tid / GRID_LANES_PER_SOLVE;",
+                "int gpb = (blockDim.x*blockDim.y) / GRID_LANES_PER_SOLVE; if (gpb > " + max_groups_const + ") {gpb = " + max_groups_const + ";}"]
+    self.gen_add_code_lines(head + [
         "if (grp >= gpb) {return;}",
         "T *s_mem = reinterpret_cast<T *>(grid_smem_raw) + grp*" + lds_per_solve_const + ";",
         "// output staging lives behind this block's slices so that the records of a wave's lane groups are contiguous",

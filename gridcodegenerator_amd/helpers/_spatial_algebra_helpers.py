@@ -43,6 +43,10 @@ __device__ __forceinline__ void grid_pin6(T (&v)[6]) {
     for (int r = 0; r < 6; r++) { asm("" : "+v"(v[r])); }
 }
 
+// value of x on the lane that owns joint `src` of THIS solve (cross-lane read inside the lane group, no LDS storage)
+template <typename V>
+__device__ __forceinline__ V grid_group_shfl(const V x, const int src) { @@GROUP_SHFL@@ }
+
 // 16-byte global store of a finished output record chunk (the address is only 4-byte aligned in general; gfx950 handles that)
 template <typename T>
 __device__ __forceinline__ void grid_store4(T *dst, const T (&v)[4]) { @@STORE4@@ }
@@ -167,6 +171,10 @@ def gen_spatial_algebra_helpers(self):
     if self.tuning["nt_store"]:  # streaming (non-temporal) output stores: the record is never re-read by the kernel (+2 % on the 7-DoF arm)
         store4 = ("\n#if defined(__HIP_DEVICE_COMPILE__)\n    typedef T vec4_t __attribute__((ext_vector_type(4), aligned(4))); vec4_t x = {v[0], v[1], v[2], v[3]}; "
                   "__builtin_nontemporal_store(x, reinterpret_cast<vec4_t *>(dst));\n#else\n    __builtin_memcpy(dst, v, 4*sizeof(T));\n#endif\n")
+    if getattr(self, "lane_interleave", False):  # thread t of a 16-lane row: solve t & 1, joint t >> 1
+        lib = lib.replace("@@GROUP_SHFL@@", "const int wl = __lane_id(); return __shfl(x, (wl & 0x31) | (src << 1), 64);")
+    else:
+        lib = lib.replace("@@GROUP_SHFL@@", "return __shfl(x, src, %d);" % self.lanes_per_solve)
     for line in lib.replace("@@STORE4@@", store4).strip("\n").split("\n"):
         self.gen_add_code_line(line)
     self.gen_add_code_line("")

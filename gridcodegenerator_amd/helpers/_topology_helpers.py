@@ -158,6 +158,10 @@ def gen_model_constant_table(self):
         it = self.gen_idsva_so_items_table()
         self.gen_add_code_line("// work items (c, m) of the second-order main loops, [lane][slot] (algorithms/_idsva_so.py: gen_idsva_so_items)")
         self.gen_add_code_line("__device__ const int grid_so_items[%d] = {%s};" % (len(it), ", ".join(str(int(x)) for x in it)))
+    if self.gen_idsva_so_mode() is not None and self.gen_fdsva_so_components() is not None:
+        flat, _ = self.gen_fdsva_so_components()
+        self.gen_add_code_line("// base-rooted component of every joint: first joint, size (algorithms/_fdsva_so.py: the contraction of fdsva_so is block diagonal over the components)")
+        self.gen_add_code_line("__device__ const int grid_so_component[%d] = {%s};" % (len(flat), ", ".join(str(int(x)) for x in flat)))
     if self.gen_idsva_so_mode() is not None and self.gen_idsva_so_compact():
         L = self.gen_idsva_so_compact_layout()
         self.gen_add_code_line("// slot of every element of the dense second-order record in the compact staging record (algorithms/_idsva_so.py: gen_idsva_so_compact_layout)")

@@ -124,6 +124,7 @@ inline V shfl(V v, int src, int width) {
 }
 }  // namespace hipemu
 #define __shfl(v, src, width) hipemu::shfl((v), (src), (width))
+inline int __lane_id() { return static_cast<int>((threadIdx.x + threadIdx.y * blockDim.x) & 63u); }  // lane inside the wavefront (waves = 64 consecutive threads of a block)
 // DPP row shifts (row_shr:K = 0x110+K reads lane-K, row_shl:K = 0x100+K reads lane+K, inside rows of 16 consecutive lanes); a source
 // outside the row yields 0 with bound_ctrl, else `old`.  Only what the generated code uses (full row/bank masks).
 namespace hipemu {

@@ -153,7 +153,7 @@ def test_waves_past_the_end_of_a_ragged_batch_write_nothing(N, threads, golden):
     reps = -(-N // 16)
     x = np.ascontiguousarray(np.tile(np.hstack([g["q"], g["qd"], g["u"]]).astype(np.float32), (reps, 1))[:N])
     ref = np.tile(np.stack([g["df_du"][k].T.reshape(-1) for k in range(16)]), (reps, 1))[:N]
-    gpb = min(threads // 8, 32)
+    gpb = min(threads // 16 * 2, 32)  # (8-lane groups interleave pairwise in 16-lane rows: blocks are whole rows)
     try:
         for blocks in (0, 1):  # 1: grid-stride, the staging area still holds the previous trip's records
             lib.set_launch_dims(blocks, threads)

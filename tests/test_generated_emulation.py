@@ -88,7 +88,51 @@ def test_emulated_generation_variants(name, tuning, golden):
     assert per_solve_err(dc, np.stack([g["dc_du"][k].T.reshape(-1) for k in range(N)])) <= TOL
 
 
-@pytest.mark.parametrize("blocks,threads", [(1, 64), (2, 24), (1, 8), (3, 40)])
+@pytest.mark.parametrize("name", ["iiwa14", "arm6", "hyq", "mixed5", "atlas"])
+def test_emulated_non_finite_solves_do_not_leak_into_their_neighbours(name, libs, golden):
+    """the lane-group scans multiplied the value shifted in from beyond a group's end by a mask of 0 - with 8-lane groups the neighbour in the
+    16-lane DPP row is ANOTHER solve, and 0 * NaN (or 0 * Inf) from a diverged trajectory point turned a healthy neighbour's gradient into NaN (the
+    reference, one block per solve, keeps solves independent).  8-lane groups now interleave the two solves of a row (GRID_LANE_INTERLEAVE): a row shift
+    never reaches the other solve.  A NaN in qd of one solve and an Inf in q of another: every other record stays bit-identical, in every kernel."""
+    g = golden(name)
+    lib = libs(name)
+    n = lib.n
+    N = 8
+    x = np.ascontiguousarray(np.hstack([g["q"], g["qd"], g["u"]]).astype(np.float32)[:N])
+    qdd = np.ascontiguousarray(g["qdd"].astype(np.float32)[:N])
+    bad = x.copy()
+    bad[2, n + 1] = np.nan      # qd of solve 2
+    bad[5, 0] = np.inf          # q of solve 5
+    bad[7, 2 * n] = 1e38        # u of solve 7: overflows on the way
+    keep = [k for k in range(N) if k not in (2, 5, 7)]
+    lib.set_launch_dims(0, 64)
+
+    def run(inp):
+        outs = [lib.forward_dynamics_gradient_host(inp)]
+        for fn, cols, args in ((lib.inverse_dynamics_device, n, (qdd,)), (lib.inverse_dynamics_gradient_device, 2 * n * n, (qdd,))):
+            o = np.zeros((N, cols), np.float32)
+            fn(inp, *args, N, o)
+            outs.append(o)
+        for fn, cols in ((lib.forward_dynamics_device, n), (lib.aba_device, n), (lib.direct_minv_device, n * n)):
+            o = np.zeros((N, cols), np.float32)
+            fn(inp, N, o)
+            outs.append(o)
+        if lib.has_second_order and n <= 12:
+            for fn, args in ((lib.idsva_so_device, (qdd,)), (lib.fdsva_so_device, ())):
+                o = np.zeros((N, 4 * n ** 3), np.float32)
+                fn(inp, *args, N, o)
+                outs.append(o)
+        return outs
+
+    clean, dirty = run(x), run(bad)
+    lib.set_launch_dims(0, 0)
+    for c, d in zip(clean, dirty):
+        assert np.isfinite(c).all()
+        assert np.array_equal(c[keep], d[keep])
+    assert not np.isfinite(dirty[0][2]).all()  # (the poisoned solve itself does come out non-finite)
+
+
+@pytest.mark.parametrize("blocks,threads", [(1, 64), (2, 32), (1, 16), (3, 48)])
 def test_emulated_ragged_launch_dims_and_grid_stride(blocks, threads, libs, golden):
     g = golden("iiwa14")
     lib = libs("iiwa14")
@@ -106,6 +150,8 @@ def test_emulated_bad_launch_dims_are_rejected(libs):
     lib = libs("iiwa14")
     with pytest.raises(GridError):
         lib.set_launch_dims(1, 4)  # fewer threads than one lane group
+    with pytest.raises(GridError):
+        lib.set_launch_dims(1, 8)  # 8-lane groups interleave pairwise in 16-lane rows (GRID_LANE_INTERLEAVE): the smallest block is one row
     with pytest.raises(GridError):
         lib.set_launch_dims(1, 1024)  # beyond __launch_bounds__
     lib.set_launch_dims(0, 0)
@@ -244,7 +290,7 @@ def test_emulated_idsva_so_subtree_mapping_variant(name, golden):
     for k in range(N):
         for t in range(4):
             p, r = outs[0][k].reshape(4, -1)[t], outs[1][k].reshape(4, -1)[t]
-            assert np.abs(p - r).max() <= 2e-6 * np.abs(r).max()
+            assert np.abs(p - r).max() <= 2e-5 * np.abs(r).max()  # (trees: the shipped form also works about every joint's own origin, the variants about the base origin)
 
 
 def test_emulated_second_order_narrow_and_wide_lane_groups_agree(golden):

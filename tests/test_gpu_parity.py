@@ -89,7 +89,7 @@ def test_host_entry_point_and_grid_stride(torch_cuda, libs):
     ref, _ = Oracle(robot).fd_grad_batch(x.astype(np.float64))
     out = lib.forward_dynamics_gradient_host(x)
     assert per_solve_err(out, ref) <= TOL
-    for blocks, threads in [(3, 256), (7, 64), (5, 96), (2, 512), (9, 40), (4, 24), (64, 8), (1, 504), (0, 200)]:  # fewer blocks than batches -> grid-stride; ragged block sizes (partial last waves)
+    for blocks, threads in [(3, 256), (7, 64), (5, 96), (2, 512), (9, 40), (4, 24), (64, 16), (1, 504), (0, 200)]:  # fewer blocks than batches -> grid-stride; ragged block sizes (partial last waves; whole 16-lane rows are used)
         lib.set_launch_dims(blocks, threads)
         out = lib.forward_dynamics_gradient_host(x)
         assert per_solve_err(out, ref) <= TOL, (blocks, threads)
@@ -322,7 +322,7 @@ def test_idsva_so_matches_the_restated_reference_algorithm(name, torch_cuda, lib
         torch.cuda.synchronize()
         got = out.cpu().numpy()
         assert np.isfinite(got).all()  # every entry is written exactly once
-        for k in range(min(N, 4)):
+        for k in range(N):  # every golden state
             ref = idsva_so(model, xh[k, :n].astype(np.float64), xh[k, n:2 * n].astype(np.float64), qh[k].astype(np.float64) if use_qdd else np.zeros(n))
             for t in range(4):
                 assert np.abs(got[k].reshape(4, n, n, n)[t] - ref[t]).max() <= TOL * max(np.abs(ref[t]).max(), 1e-3), (k, t)
@@ -381,7 +381,7 @@ def test_fdsva_so_matches_the_restated_reference_algorithm(name, torch_cuda, lib
     assert np.isfinite(got).all()
     robot = RobotModel.from_fixture(name)
     model, orc = DuckRobot(robot), Oracle(robot)
-    for k in range(min(N, 3)):
+    for k in range(N):  # every golden state
         q, qd, u = (xh[k, i * n:(i + 1) * n].astype(np.float64) for i in range(3))
         df_du, qdd, Minv, _ = orc.fd_grad(q, qd, u, full=True)
         so = np.concatenate([t.reshape(-1) for t in idsva_so(model, q, qd, qdd)])
@@ -415,6 +415,80 @@ def _sweep_errors(torch, lib, robot, dist, N, seed):
         ref, _ = orc.fd_grad_batch(x.astype(np.float64))
         errs.append(np.abs(out - ref).max(axis=1) / np.abs(ref).max(axis=1))
     return np.concatenate(errs)
+
+
+@pytest.mark.parametrize("name", ["iiwa14", "arm6", "hyq", "atlas", "mixed5"])
+def test_non_finite_solves_do_not_leak_into_their_neighbours(name, torch_cuda, libs, golden):
+    """ADVICE r2 (see tests/test_generated_emulation.py: same test on the emulation): one diverged trajectory point - NaN in qd, Inf in q, a torque that
+    overflows - must not change any other record of the batch (the reference runs one block per solve).  8-lane groups interleave the two solves of a
+    16-lane DPP row, so the lane-group scans never touch the other solve's values."""
+    torch = torch_cuda
+    g = golden(name)
+    lib = libs(name)
+    n = lib.n
+    N = 8
+    st = torch.cuda.current_stream().cuda_stream
+    x = np.ascontiguousarray(np.hstack([g["q"], g["qd"], g["u"]]).astype(np.float32)[:N])
+    qdd = torch.from_numpy(np.ascontiguousarray(g["qdd"].astype(np.float32)[:N])).cuda()
+    bad = x.copy()
+    bad[2, n + 1] = np.nan
+    bad[5, 0] = np.inf
+    bad[7, 2 * n] = 1e38
+    keep = [k for k in range(N) if k not in (2, 5, 7)]
+
+    def run(inp):
+        d = torch.from_numpy(inp).cuda()
+        outs = []
+        for fn, cols, args in ((lib.forward_dynamics_gradient_device, 2 * n * n, ()), (lib.forward_dynamics_device, n, ()), (lib.aba_device, n, ()), (lib.direct_minv_device, n * n, ())):
+            o = torch.zeros((N, cols), dtype=torch.float32, device="cuda")
+            if fn == lib.direct_minv_device:
+                fn(d, N, o, stream=st)
+            else:
+                fn(d, *args, N, o, stream=st)
+            outs.append(o)
+        for fn, cols in ((lib.inverse_dynamics_device, n), (lib.inverse_dynamics_gradient_device, 2 * n * n)):
+            o = torch.zeros((N, cols), dtype=torch.float32, device="cuda")
+            fn(d, qdd, N, o, stream=st)
+            outs.append(o)
+        if lib.has_second_order:
+            o = torch.zeros((N, 4 * n ** 3), dtype=torch.float32, device="cuda")
+            lib.idsva_so_device(d, qdd, N, o, stream=st)
+            outs.append(o)
+            o = torch.zeros((N, 4 * n ** 3), dtype=torch.float32, device="cuda")
+            lib.fdsva_so_device(d, N, o, stream=st)
+            outs.append(o)
+        torch.cuda.synchronize()
+        return [o.cpu().numpy() for o in outs]
+
+    clean, dirty = run(x), run(bad)
+    for c, d in zip(clean, dirty):
+        assert np.isfinite(c).all()
+        assert np.array_equal(c[keep], d[keep])
+    assert not np.isfinite(dirty[0][2]).all()
+
+
+@pytest.mark.parametrize("name,states", [("iiwa14", 2048), ("arm6", 1024), ("hyq", 2048), ("tree12", 2048), ("atlas", 128)])
+def test_fp32_error_tail_of_the_second_order_kernels_is_guarded(name, states, torch_cuda):
+    """the second-order kernels chain the explicit-M factorisation of the first-order path with an n^4 contraction; their fp32 tail had only ever
+    been looked at on 12 solves per robot (fdsva_so on the 12-DoF tree: 5.45e-5 of the 1e-4 bar).  This sweep runs idsva_so (random qdd) and fdsva_so on
+    `states` random states - half from the bench distribution, half wide (q +-10 pi, qd +-10, u +-100) - and checks EVERY solve against the NumPy
+    restatements of the reference's emitters (tests/so_sweep.py; PARITY UNPINNED: the reference holds no vectors for these algorithms).
+    Per solve and tensor: max|got - ref| <= 1e-4 max(max|ref|, 1e-3).  tests/tools/parity_sweep_second_order.py prints max / p99.9 of the same sweep."""
+    import so_sweep
+
+    robot = RobotModel.from_fixture(name)
+    N = states // 2
+    lib = GridLibrary(build_library(name), device=0, max_timesteps=N)
+    try:
+        for dist, seed in (("bench", 7), ("wide", 8)):
+            x, qdd = so_sweep.so_inputs(robot.n, N, dist, seed)
+            so, f2 = so_sweep.run_so(torch_cuda, lib, x, qdd)
+            assert np.isfinite(so).all() and np.isfinite(f2).all()
+            e_so, e_f2 = so_sweep.so_errors(name, x, qdd, so, f2)
+            assert e_so.max() <= TOL, (name, dist, "idsva_so", e_so.max(), int(e_so.argmax()))
+            assert e_f2.max() <= TOL, (name, dist, "fdsva_so", e_f2.max(), int(e_f2.argmax()))
+    finally:
+        lib.close()
 
 
 @pytest.mark.parametrize("name,max_tol,p999_tol", [("iiwa14", 3e-5, 1e-5), ("arm6", 3e-5, 1e-5), ("hyq", 3e-5, 1e-5), ("atlas", 6e-5, 1.5e-5)])
