@@ -18,6 +18,7 @@ struct grid_capi_error {
 
 #include <string.h>
 
+#include <mutex>
 #include <new>
 #include <string>
 #include <thread>
@@ -41,6 +42,11 @@ struct grid_handle {
     hipStream_t *streams;
     grid_typed<float> f32;
     grid_typed<double> f64;  // allocated by the first *_f64 call
+    std::mutex alloc_lock;   // serialises that lazy allocation (two threads making their first *_f64 call on one handle)
+    // GRID_SO_DIRECT (records beyond the LDS of a CU): fdsva_so keeps the idsva_so tensors in the handle's ONE d_idsva_so workspace.  Calls on different streams
+    // (or threads) are made safe by ordering them: every launch waits for the previous one's event before it may touch the workspace
+    hipEvent_t so_done = nullptr;
+    bool so_pending = false;
 };
 template <typename T> static inline grid_typed<T> &typed(grid_handle *h);
 template <> inline grid_typed<float> &typed<float>(grid_handle *h) { return h->f32; }
@@ -137,6 +143,18 @@ static int general_launch(const grid_handle *h, int num_timesteps, launch_cfg *c
     return make_launch<T>(h, num_timesteps, grid::SUGGESTED_THREADS, grid::GRID_MAX_SOLVES_PER_BLOCK, grid::GRID_LDS_PER_SOLVE, grid::GRID_OUT_PER_SOLVE, cfg);
 }
 
+// device entry points: required pointers must not be NULL and the stride must cover what the kernel loads per solve (a smaller or negative stride
+// would make the last solves read before / past the caller's buffer: a GPU memory fault instead of an error code)
+static int check_io(const void *in, int stride, int min_stride, const void *out, int num_timesteps) {
+    if (num_timesteps <= 0) return 0;
+    if (!in || !out) return fail_msg(hipErrorInvalidValue, "null input or output pointer");
+    if (stride < min_stride) {
+        snprintf(g_err, sizeof(g_err), "stride %d is smaller than the %d values the kernel reads per solve", stride, min_stride);
+        return (int)hipErrorInvalidValue;
+    }
+    return 0;
+}
+
 static int check_args(const grid_handle *h, int num_timesteps) {
     if (!h) return fail_msg(hipErrorInvalidValue, "null handle");
     if (num_timesteps < 0) return fail_msg(hipErrorInvalidValue, "negative num_timesteps");
@@ -174,6 +192,7 @@ static int so_capacity(const grid_handle *h) {
 template <typename T>
 static int ensure_typed(grid_handle *h) {
     grid_typed<T> &t = typed<T>(h);
+    std::lock_guard<std::mutex> lock(h->alloc_lock);
     if (t.hd_data) return 0;
     size_t free_b = 0, total_b = 0;
     GRID_TRY(hipMemGetInfo(&free_b, &total_b));
@@ -192,6 +211,7 @@ template <typename T>
 static int fd_grad_device(grid_handle *h, const T *d_q_qd_u, int stride, int N, T gravity, T *d_df_du, void *stream) {
     int rc = check_args(h, N);
     if (rc) return rc;
+    if ((rc = check_io(d_q_qd_u, stride, 3*(int)grid::NUM_JOINTS, d_df_du, N))) return rc;
     if (N == 0) return 0;
     GRID_ON_DEVICE(h);
     if ((rc = ensure_typed<T>(h))) return rc;
@@ -208,6 +228,8 @@ template <typename T>
 static int fd_grad_qdd_minv_device(grid_handle *h, const T *d_q_qd, int stride, const T *d_qdd, const T *d_Minv, int N, T gravity, T *d_df_du, void *stream) {
     int rc = check_args(h, N);
     if (rc) return rc;
+    if ((rc = check_io(d_q_qd, stride, 2*(int)grid::NUM_JOINTS, d_df_du, N))) return rc;
+    if (N > 0 && (!d_qdd || !d_Minv)) return fail_msg(hipErrorInvalidValue, "null qdd or Minv pointer");
     if (N == 0) return 0;
     GRID_ON_DEVICE(h);
     if ((rc = ensure_typed<T>(h))) return rc;
@@ -223,6 +245,7 @@ template <typename T>
 static int id_device(grid_handle *h, const T *d_q_qd, int stride, const T *d_qdd, int N, T gravity, T *d_c, void *stream) {
     int rc = check_args(h, N);
     if (rc) return rc;
+    if ((rc = check_io(d_q_qd, stride, 2*(int)grid::NUM_JOINTS, d_c, N))) return rc;
     if (N == 0) return 0;
     GRID_ON_DEVICE(h);
     if ((rc = ensure_typed<T>(h))) return rc;
@@ -241,6 +264,7 @@ template <typename T>
 static int id_grad_device(grid_handle *h, const T *d_q_qd, int stride, const T *d_qdd, int N, T gravity, T *d_dc_du, void *stream) {
     int rc = check_args(h, N);
     if (rc) return rc;
+    if ((rc = check_io(d_q_qd, stride, 2*(int)grid::NUM_JOINTS, d_dc_du, N))) return rc;
     if (N == 0) return 0;
     GRID_ON_DEVICE(h);
     if ((rc = ensure_typed<T>(h))) return rc;
@@ -261,6 +285,7 @@ template <typename T>
 static int minv_device(grid_handle *h, const T *d_q, int stride, int N, T *d_Minv, void *stream) {
     int rc = check_args(h, N);
     if (rc) return rc;
+    if ((rc = check_io(d_q, stride, 1*(int)grid::NUM_JOINTS, d_Minv, N))) return rc;
     if (N == 0) return 0;
     GRID_ON_DEVICE(h);
     if ((rc = ensure_typed<T>(h))) return rc;
@@ -275,6 +300,7 @@ template <typename T>
 static int fd_device(grid_handle *h, const T *d_q_qd_u, int stride, int N, T gravity, T *d_qdd, void *stream, bool aba) {
     int rc = check_args(h, N);
     if (rc) return rc;
+    if ((rc = check_io(d_q_qd_u, stride, 3*(int)grid::NUM_JOINTS, d_qdd, N))) return rc;
     if (N == 0) return 0;
     GRID_ON_DEVICE(h);
     if ((rc = ensure_typed<T>(h))) return rc;
@@ -293,6 +319,7 @@ template <typename T>
 static int idsva_so_device(grid_handle *h, const T *d_q_qd_u, int stride, const T *d_qdd, int N, T gravity, T *d_idsva_so, void *stream) {
     int rc = check_args(h, N);
     if (rc) return rc;
+    if ((rc = check_io(d_q_qd_u, stride, 2*(int)grid::NUM_JOINTS, d_idsva_so, N))) return rc;
 #if GRID_HAS_IDSVA_SO
     if (N == 0) return 0;
     GRID_ON_DEVICE(h);
@@ -316,6 +343,7 @@ template <typename T>
 static int fdsva_so_device(grid_handle *h, const T *d_q_qd_u, int stride, int N, T gravity, T *d_df2, void *stream) {
     int rc = check_args(h, N);
     if (rc) return rc;
+    if ((rc = check_io(d_q_qd_u, stride, 3*(int)grid::NUM_JOINTS, d_df2, N))) return rc;
 #if GRID_HAS_IDSVA_SO
     if (N == 0) return 0;
     GRID_ON_DEVICE(h);
@@ -325,7 +353,15 @@ static int fdsva_so_device(grid_handle *h, const T *d_q_qd_u, int stride, int N,
 #if GRID_SO_DIRECT
     // the idsva_so tensors of a solve do not fit LDS: the kernel keeps them in the handle's d_idsva_so buffer
     if (N > so_capacity<T>(h)) return fail_msg(hipErrorInvalidValue, "num_timesteps exceeds the handle's second-order workspace (grid_second_order_capacity)");
-    hipLaunchKernelGGL((grid_so::fdsva_so_kernel<T>), c.grid, c.block, c.lds, (hipStream_t)stream, d_df2, typed<T>(h).hd_data->d_idsva_so, d_q_qd_u, stride, reinterpret_cast<const grid_so::robotModel<T> *>(typed<T>(h).d_robotModel), gravity, N);
+    {
+        std::lock_guard<std::mutex> lock(h->alloc_lock);
+        if (!h->so_done) GRID_TRY(hipEventCreateWithFlags(&h->so_done, hipEventDisableTiming));
+        if (h->so_pending) GRID_TRY(hipStreamWaitEvent((hipStream_t)stream, h->so_done, 0));  // (the previous launch may be on another stream)
+        hipLaunchKernelGGL((grid_so::fdsva_so_kernel<T>), c.grid, c.block, c.lds, (hipStream_t)stream, d_df2, typed<T>(h).hd_data->d_idsva_so, d_q_qd_u, stride, reinterpret_cast<const grid_so::robotModel<T> *>(typed<T>(h).d_robotModel), gravity, N);
+        GRID_TRY(hipGetLastError());
+        GRID_TRY(hipEventRecord(h->so_done, (hipStream_t)stream));
+        h->so_pending = true;
+    }
 #else
     hipLaunchKernelGGL((grid_so::fdsva_so_kernel<T>), c.grid, c.block, c.lds, (hipStream_t)stream, d_df2, d_q_qd_u, stride, reinterpret_cast<const grid_so::robotModel<T> *>(typed<T>(h).d_robotModel), gravity, N);
 #endif
@@ -515,7 +551,12 @@ int grid_num_joints(void) { return grid::NUM_JOINTS; }
 const char *grid_robot_name(void) { return GRID_ROBOT_NAME; }
 int grid_lanes_per_solve(void) { return grid::GRID_LANES_PER_SOLVE; }
 int grid_suggested_threads(void) { return grid::SUGGESTED_THREADS; }
-int grid_lds_bytes_per_block(void) { return grid::FD_DU_DYNAMIC_SHARED_MEM_COUNT * (int)sizeof(float); }
+int grid_lds_bytes_per_block(void) {  // what a default forward_dynamics_gradient launch asks for (same arithmetic as make_launch)
+    grid_handle h{};
+    launch_cfg c;
+    if (make_launch<float>(&h, 1, grid::FD_DU_SUGGESTED_THREADS, grid::GRID_MAX_SOLVES_PER_BLOCK, grid::FD_DU_LDS_PER_SOLVE, grid::FD_DU_OUT_PER_SOLVE, &c)) return -1;
+    return (int)c.lds;
+}
 int grid_has_second_order(void) { return GRID_HAS_IDSVA_SO; }
 int grid_second_order_capacity(const grid_handle *h, int f64) { return h ? (f64 ? so_capacity<double>(h) : so_capacity<float>(h)) : 0; }
 const char *grid_last_error(void) { return g_err; }
@@ -556,6 +597,7 @@ int grid_close(grid_handle *h) {
             grid::close_grid<double>(none, h->f64.d_robotModel, h->f64.hd_data);
         }
         grid::close_grid<float>(h->streams, h->f32.d_robotModel, h->f32.hd_data);
+        if (h->so_done) (void)hipEventDestroy(h->so_done);
     )
     delete h;
     return 0;

@@ -161,10 +161,19 @@ class GridLibrary:
         """T = double host-buffer entry points: algorithm in {inverse_dynamics, inverse_dynamics_gradient, direct_minv, forward_dynamics, aba,
         idsva_so, fdsva_so}; arrays as for the float methods (q_qd[, qdd] / q / q_qd_u[, qdd]) in float64."""
         n = self.n
-        D = lambda a: None if a is None else np.ascontiguousarray(a, dtype=np.float64)
         P = lambda a: ctypes.c_void_p(None) if a is None else ctypes.c_void_p(a.ctypes.data)
-        a0 = D(arrays[0])
+        # same column rules as the float methods; entry points without a stride argument read exactly 3n values per solve
+        first = {"inverse_dynamics": (2 * n, 3 * n), "inverse_dynamics_gradient": (2 * n, 3 * n), "direct_minv": (n, 2 * n, 3 * n)}.get(algorithm, 3 * n)
+        a0 = self._host_in(arrays[0], first, "first input of " + algorithm, np.float64)
         N = a0.shape[0]
+
+        def D(a):
+            if a is None:
+                return None
+            x = self._host_in(a, n, "qdd", np.float64)
+            if x.shape[0] != N:
+                raise ValueError("qdd must have as many rows as the first input")
+            return x
         cols = {"inverse_dynamics": n, "inverse_dynamics_gradient": 2 * n * n, "direct_minv": n * n, "forward_dynamics": n, "aba": n,
                 "idsva_so": 4 * n ** 3, "fdsva_so": 4 * n ** 3}[algorithm]
         out = np.empty((N, cols), dtype=np.float64)
@@ -315,7 +324,7 @@ class MultiGpuGrid:
         return [(min(g * per, N), min((g + 1) * per, N)) for g in range(G)]
 
     def forward_dynamics_gradient_host(self, q_qd_u, gravity=9.81):
-        x = np.ascontiguousarray(q_qd_u, dtype=np.float32)
+        x = self.parts[0]._host_in(q_qd_u, 3 * self.n, "q_qd_u")
         N = x.shape[0]
         out = np.empty((N, 2 * self.n * self.n), dtype=np.float32)
         hs = (ctypes.c_void_p * len(self.parts))(*[p.handle for p in self.parts])

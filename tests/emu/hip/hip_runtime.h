@@ -56,6 +56,12 @@ inline hipError_t hipMemcpyAsync(void *d, const void *s, size_t n, hipMemcpyKind
 inline hipError_t hipDeviceGetStreamPriorityRange(int *lo, int *hi) { *lo = 0; *hi = 0; return hipSuccess; }
 inline hipError_t hipStreamCreateWithPriority(hipStream_t *s, unsigned, int) { *s = nullptr; return hipSuccess; }
 inline hipError_t hipStreamDestroy(hipStream_t) { return hipSuccess; }
+typedef void *hipEvent_t;  // (every emulated launch is synchronous: events are no-ops)
+enum { hipEventDisableTiming = 2 };
+inline hipError_t hipEventCreateWithFlags(hipEvent_t *e, unsigned) { *e = (void *)1; return hipSuccess; }
+inline hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return hipSuccess; }
+inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }
+inline hipError_t hipEventDestroy(hipEvent_t) { return hipSuccess; }
 
 // dynamic LDS of the (single) running block
 __attribute__((aligned(16))) unsigned char grid_smem_raw[160 * 1024];  // (one definition: the emulation harness is a single translation unit)

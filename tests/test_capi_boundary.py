@@ -203,3 +203,65 @@ def test_static_shared_memory_mode_is_rejected_not_ignored():
     cannot honour it (their LDS is sized by the launch), so the constructor refuses instead of silently ignoring the flag."""
     with pytest.raises(NotImplementedError):
         GRiDCodeGenerator(RobotModel.from_fixture("iiwa14"), USE_DYNAMIC_SHARED_MEM=False)
+
+
+def test_device_entry_points_reject_null_pointers_and_short_strides(golden):
+    """the *_device entry points validated only the handle, N and the thread count - a NULL buffer or a stride smaller than what the kernel
+    loads per solve became a GPU memory fault instead of hipErrorInvalidValue.  (Emulation: the same C-ABI shim, so the checks run without a GPU.)"""
+    import ctypes
+
+    from gridcodegenerator_amd.runtime import GridError
+
+    lib = emu_library("iiwa14", max_timesteps=16)
+    n = lib.n
+    x = np.zeros((4, 3 * n), np.float32)
+    out = np.zeros((4, 2 * n * n), np.float32)
+    qdd = np.zeros((4, n), np.float32)
+    with pytest.raises(GridError, match="null"):
+        lib.forward_dynamics_gradient_device(None, 4, out)
+    with pytest.raises(GridError, match="null"):
+        lib.forward_dynamics_gradient_device(x, 4, None)
+    for stride in (-1, 0, 2 * n, 3 * n - 1):
+        with pytest.raises(GridError, match="stride"):
+            lib.forward_dynamics_gradient_device(x, 4, out, stride=stride) if stride else lib._check(
+                lib.lib.grid_forward_dynamics_gradient_device(lib.handle, ctypes.c_void_p(x.ctypes.data), ctypes.c_int(0), ctypes.c_int(4), ctypes.c_float(9.81),
+                                                              ctypes.c_void_p(out.ctypes.data), ctypes.c_void_p(0)))
+    with pytest.raises(GridError, match="stride"):
+        lib.inverse_dynamics_device(x, qdd, 4, np.zeros((4, n), np.float32), stride=n)       # needs q | qd
+    with pytest.raises(GridError, match="stride"):
+        lib.direct_minv_device(x, 4, np.zeros((4, n * n), np.float32), stride=n - 1)
+    with pytest.raises(GridError, match="stride"):
+        lib.fdsva_so_device(x, 4, np.zeros((4, 4 * n ** 3), np.float32), stride=2 * n)        # needs q | qd | u
+    with pytest.raises(GridError, match="null"):
+        lib.forward_dynamics_gradient_qdd_minv_device(x, None, np.zeros((4, n * n), np.float32), 4, out)
+    lib.forward_dynamics_gradient_device(None, 0, None)  # an empty batch touches nothing
+    lib.forward_dynamics_gradient_device(x, 4, out)
+    assert np.isfinite(out).all()
+    assert lib.lds_bytes_per_block == (lib.suggested_threads // lib.lanes_per_solve) * (lib.lib.grid_lds_bytes_per_block() // (lib.suggested_threads // lib.lanes_per_solve))
+    assert 0 < lib.lds_bytes_per_block <= 160 * 1024
+
+
+def test_double_precision_and_multi_device_wrappers_check_their_array_shapes():
+    """host_f64() and MultiGpuGrid passed arrays of any width on to C entry points that read 3n values per solve."""
+    from gridcodegenerator_amd.runtime import MultiGpuGrid
+
+    lib = emu_library("iiwa14", max_timesteps=16)
+    n = lib.n
+    for alg in ("forward_dynamics", "aba", "idsva_so", "fdsva_so"):
+        with pytest.raises(ValueError):
+            lib.host_f64(alg, np.zeros((3, 2 * n)))
+    with pytest.raises(ValueError):
+        lib.host_f64("inverse_dynamics", np.zeros((3, n)))
+    with pytest.raises(ValueError):
+        lib.host_f64("inverse_dynamics", np.zeros((3, 2 * n)), np.zeros((3, n + 1)))
+    with pytest.raises(ValueError):
+        lib.host_f64("idsva_so", np.zeros((3, 3 * n)), np.zeros((2, n)))
+    assert lib.host_f64("inverse_dynamics", np.zeros((3, 2 * n)), np.zeros((3, n))).shape == (3, n)
+    multi = MultiGpuGrid(lib.path, devices=[0, 1], max_timesteps=16)
+    try:
+        with pytest.raises(ValueError):
+            multi.forward_dynamics_gradient_host(np.zeros((4, 2 * n), np.float32))
+        with pytest.raises(ValueError):
+            multi.forward_dynamics_gradient_host(np.zeros(3 * n, np.float32))
+    finally:
+        multi.close()
