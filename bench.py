@@ -114,6 +114,15 @@ def reduce_max(elapsed, dist, device):
     return float(t.item())
 
 
+def reduce_min_max(elapsed, dist, device):
+    """(min, max) of the ranks' elapsed times: max is the job's time, min shows how far the fastest rank was ahead (a straggler in a scaling curve)."""
+    import torch
+
+    t = torch.tensor([-elapsed, elapsed], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(-t[0].item()), float(t[1].item())
+
+
 def harness_selftest(args):
     """Multi-rank plumbing only (gloo, CPU): no kernels, no metric.  Checks that the ranks' shards are what the scaling mode defines:
     strong -> the concatenation of the ranks' slices IS the one global batch; weak -> pairwise distinct batches."""
@@ -133,13 +142,13 @@ def harness_selftest(args):
     dist.barrier()
     t0 = time.perf_counter()
     time.sleep(0.01 * (rank + 1))  # rank-dependent "work": the reported time must be the slowest rank's
-    elapsed = reduce_max(time.perf_counter() - t0, dist, torch.device("cpu"))
+    fastest, elapsed = reduce_min_max(time.perf_counter() - t0, dist, torch.device("cpu"))
     dist.barrier()
     if rank == 0:
         ranges = [(int(i[0]), int(i[1])) for i in infos]
         total_checksum = float(sum(i[3] for i in infos))
         global_checksum = float(np.abs(make_inputs(n, N, seed=0).astype(np.float64)).sum())
-        print(json.dumps({"selftest": "bench harness", "n_gpus": world, "scaling": args.scaling, "max_elapsed_s": elapsed,
+        print(json.dumps({"selftest": "bench harness", "n_gpus": world, "scaling": args.scaling, "max_elapsed_s": elapsed, "per_rank_ms": {"min": 1e3 * fastest, "max": 1e3 * elapsed},
                           "ranges": ranges, "rows": [int(i[2]) for i in infos],
                           "contiguous_cover": args.scaling == "strong" and ranges[0][0] == 0 and ranges[-1][1] == N and all(ranges[i][1] == ranges[i + 1][0] for i in range(world - 1)),
                           "shards_sum_to_global_batch": abs(total_checksum - global_checksum) <= 1e-9 * global_checksum,
@@ -269,8 +278,9 @@ def main():
         gc.enable()
         barrier()
         gpu_ms = ev0.elapsed_time(ev1)
+        fastest = elapsed
         if distributed:
-            elapsed = reduce_max(elapsed, dist, red_dev)  # job time = slowest rank (all ranks started together behind the opening barrier)
+            fastest, elapsed = reduce_min_max(elapsed, dist, red_dev)  # job time = slowest rank (all ranks started together behind the opening barrier)
         # ---- diagnostic pass (not part of `value`): an event every CHUNK launches -> distribution of the per-launch time.  (An event after
         # every single launch puts a marker packet between the kernels that costs ~3 us, more than a third of the kernel itself.)
         CHUNK = 4
@@ -285,7 +295,7 @@ def main():
         per = np.array([evs[i].elapsed_time(evs[i + 1]) for i in range(nch)]) * 1e3 / CHUNK  # us per launch, chunk means
         barrier()
         total = (B if scaling == "strong" else world * B) * steps
-        return {"x": x, "d_out": d_out, "N": N, "elapsed": elapsed, "gpu_ms": gpu_ms, "per_launch_us": per, "solves": total,
+        return {"x": x, "d_out": d_out, "N": N, "elapsed": elapsed, "fastest": fastest, "gpu_ms": gpu_ms, "per_launch_us": per, "solves": total,
                 "warm_launches": warm_launches}
 
     scaling = args.scaling
@@ -330,6 +340,8 @@ def main():
                        "robot": ROBOT, "batch_per_gpu": N, "global_batch": B if scaling == "strong" else world * B,
                        "sharding": "contiguous ranges of the batch axis (ceil(B/G) solves per GPU), no collective" if scaling == "strong" else "one batch per GPU, no collective"},
             "clock_warm_ms": args.clock_warm_ms, "clock_warm_launches": r["warm_launches"],
+            # wall time of the K steps on the fastest and on the slowest rank (the job's time is the slowest): a straggler shows as a wide gap
+            "per_rank_ms": {"min": 1e3 * r["fastest"], "max": 1e3 * r["elapsed"], "per_step_min": 1e3 * r["fastest"] / args.steps, "per_step_max": 1e3 * r["elapsed"] / args.steps},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_source": (PMC_FILE + " (rocprofv3 --pmc passes of this kernel build, not measured in this run)") if traffic else None,
                          "kernel": "forward_dynamics_gradient_kernel<float>", "launch_us": 1e3 * launch_ms,

@@ -30,14 +30,16 @@ def gen_idsva_so_mode(self):
     """"chain": a single serial chain of revolute joints - the tip-frame formulation (lane scans, no LDS hand-offs in the set-up);
     "tree": any other fixed-base robot with revolute joints - one common (base) frame, the kinematics
     and the subtree composites travel level by level through LDS (reference: get_parent_id tables, algorithms/_idsva_so.py:171-193,264-284,320-340);
-    None: not emitted (prismatic joints).  Records beyond the LDS of a CU (30 joints: 432 KB per solve - the reference's own kernel keeps
+    None: not emitted (one derivative column per lane; prismatic joints under the round-2 tuning variants).  Records beyond the LDS of a CU (30 joints: 432 KB per solve - the reference's own kernel keeps
     4 n^3 + 390 n + 36 |pairs| values in shared memory, ~500 KB there, and cannot be launched on any GPU) are written straight to global
     memory: gen_idsva_so_direct()."""
     if getattr(self, "tip_frame", False) and self.tip_nseg == 1:
         return "chain"
     m = self.model
-    if self.cols_per_lane != 2 or any(s_ >= 3 for s_ in m.S_index):
+    if self.cols_per_lane != 2:
         return None
+    if any(s_ >= 3 for s_ in m.S_index) and not (self.tuning["so_origin"] == "joint" and self.tuning["so_mapping"] == "balanced" and self.tuning["so_loops"] == "dots"):
+        return None  # (prismatic joints: only the form that keeps every joint's quantities about its own origin carries the joint type through the records)
     return "tree"
 
 
@@ -323,6 +325,7 @@ class _SoStores:
 
 
 def _so_emit_balanced_main_dots(self, tree, compact, local=False):
+    has_pris = any(s_ >= 3 for s_ in self.model.S_index)
     """Main loops, balanced mapping (gen_idsva_so_items), dot-product form (see _SO_FOLD); expects the per-lane quantities of _SO_PREP (lane <-> joint) and
     the records [S | Pd | Pdd | parent] in s_X.  Writes through `so`: the dense record (LDS or global memory) or the compact staging record."""
     n, G = self.model.n, self.lanes_per_solve
@@ -352,7 +355,7 @@ def _so_emit_balanced_main_dots(self, tree, compact, local=False):
     for (int r = 0; r < 6; r++) { yS[r] = s_X[20*m + r]; yP[r] = s_X[20*m + 6 + r]; yPP[r] = s_X[20*m + 12 + r]; }""",
                                                  """    T yS[6], yP[6], yPP[6];
     { const T *ry = &s_X[20*m]; const T qm[3] = {pc[0] - ry[3], pc[1] - ry[4], pc[2] - ry[5]};
-      grid_so_axis_at(yS, ry, qm); grid_so_motion_at(yP, ry + 6, qm); grid_so_motion_at(yPP, ry + 12, qm); }"""))
+      @YAXIS@ grid_so_motion_at(yP, ry + 6, qm); grid_so_motion_at(yPP, ry + 12, qm); }""".replace("@YAXIS@", "grid_so_joint_axis_at(yS, ry, qm, ry[19] != static_cast<T>(0));" if has_pris else "grid_so_axis_at(yS, ry, qm);")))
         else:
             _so_emit(self, _SO_OPERATORS)
         _so_emit(self, _SO_FOLD)
@@ -361,18 +364,21 @@ def _so_emit_balanced_main_dots(self, tree, compact, local=False):
             A("#pragma unroll")
             A("for (int r = 0; r < 6; r++) { %s[r] = s_X[20*%s + r]; %s[r] = s_X[20*%s + 6 + r]; }" % (dst_s, lv, dst_p, lv))
             A("%s%s = %s;" % ("const int " if decl else "", dst_par, par(lv)))
+            if local and has_pris:
+                A("%s%s = s_X[20*%s + 19]; // joint type" % ("const T " if decl else "", dst_par.replace("par", "typ"), lv))
 
         def xvec():  # the step's vectors S_l, Pd_l from the fetched record words
             if local:
                 A("T xS[6], xP[6];")
-                A("{ const T ql[3] = {pc[0] - rS[3], pc[1] - rS[4], pc[2] - rS[5]}; grid_so_axis_at(xS, rS, ql); grid_so_motion_at(xP, rP, ql); }")
+                A("{ const T ql[3] = {pc[0] - rS[3], pc[1] - rS[4], pc[2] - rS[5]}; %s grid_so_motion_at(xP, rP, ql); }" %
+                  ("grid_so_joint_axis_at(xS, rS, ql, ltyp != static_cast<T>(0));" if has_pris else "grid_so_axis_at(xS, rS, ql);"))
             else:
                 A("const T (&xS)[6] = rS; const T (&xP)[6] = rP;")
 
         A("if (own && c != m) { %s } // dM_dq[m][c][m]: the step l = m of the ancestor loop" % st.mq("m", "c", "m", "tm", "y_d1S"))
         # ---- path loop: joint j = l walks c -> m, ancestor-or-self an = m
         A("{ // joint j = l walks the path c -> m, ancestor-or-self an = m; the record of the next joint is fetched while this one is worked on", True)
-        A("int l = c, lpar; bool va = true;")
+        A("int l = c, lpar; bool va = true;" + (" T ltyp;" if (local and has_pris) else ""))
         A("T rS[6], rP[6];")
         fetch("rS", "rP", "lpar", "l", False)
         A("#pragma unroll 1")
@@ -396,7 +402,7 @@ def _so_emit_balanced_main_dots(self, tree, compact, local=False):
         A(st.sym("qd2", "j", "an", "c", "tc", "s_d3S"))
         A(st.vq("j", "c", "an", "s_eV"))
         self.gen_add_end_control_flow()
-        A("l = ln; va = more; lpar = npar;")
+        A("l = ln; va = more; lpar = npar;" + (" ltyp = ntyp;" if (local and has_pris) else ""))
         A("#pragma unroll")
         A("for (int r = 0; r < 6; r++) { rS[r] = nS[r]; rP[r] = nP[r]; }")
         self.gen_add_end_control_flow()
@@ -404,7 +410,7 @@ def _so_emit_balanced_main_dots(self, tree, compact, local=False):
         # ---- ancestor loop: joint j = m, proper ancestor an = l walks parent(m) -> root
         if tB[sl] > 0:
             A("{ // joint j = m, proper ancestor an = l walks parent(m) -> root", True)
-            A("int l = %s, lpar; bool va = l >= 0; if (!va) { l = 0; }" % par("m"))
+            A("int l = %s, lpar; bool va = l >= 0; if (!va) { l = 0; }" % par("m") + (" T ltyp;" if (local and has_pris) else ""))
             A("T rS[6], rP[6];")
             fetch("rS", "rP", "lpar", "l", False)
             A("#pragma unroll 1")
@@ -428,7 +434,7 @@ def _so_emit_balanced_main_dots(self, tree, compact, local=False):
             A(st.vq("an", "c", "j", "s_eV"))
             A(st.mq("an", "c", "j", "tm", "s_d1S"))
             self.gen_add_end_control_flow()
-            A("l = ln; va = more; lpar = npar;")
+            A("l = ln; va = more; lpar = npar;" + (" ltyp = ntyp;" if (local and has_pris) else ""))
             A("#pragma unroll")
             A("for (int r = 0; r < 6; r++) { rS[r] = nS[r]; rP[r] = nP[r]; }")
             self.gen_add_end_control_flow()
@@ -658,6 +664,13 @@ __device__ __forceinline__ void grid_so_axis_at(T (&y)[6], const T *w, const T (
     y[0] = w[0]; y[1] = w[1]; y[2] = w[2];
     y[3] = w[1]*q[2] - w[2]*q[1]; y[4] = w[2]*q[0] - w[0]*q[2]; y[5] = w[0]*q[1] - w[1]*q[0];
 }
+// motion subspace of a joint whose frame origin is the old reference point: revolute [w; w x q], prismatic [0; w] (a free vector)
+template <typename T>
+__device__ __forceinline__ void grid_so_joint_axis_at(T (&y)[6], const T *w, const T (&q)[3], const bool prismatic) {
+    const T z = static_cast<T>(0);
+    y[0] = prismatic ? z : w[0]; y[1] = prismatic ? z : w[1]; y[2] = prismatic ? z : w[2];
+    y[3] = prismatic ? w[0] : (w[1]*q[2] - w[2]*q[1]); y[4] = prismatic ? w[1] : (w[2]*q[0] - w[0]*q[2]); y[5] = prismatic ? w[2] : (w[0]*q[1] - w[1]*q[0]);
+}
 // y += [I^C (10) | B^C (12) | f^C (6)] of a subtree, moved to the new reference point (rigid-body inertia: h' = h - m q, parallel axes;
 // Coriolis matrix [Sym | n | l]: Sym' = Sym + l q^T + q l^T - 2 (q.l) 1, n' = n - q x l; force [n; f]: n' = n - q x f)
 template <typename T>
@@ -728,12 +741,22 @@ def gen_idsva_so_inner_tree(self, use_thread_group=False):
     A("#pragma unroll")
     A("for (int r = 0; r < 9; r++) { E[r] = has ? s_X[GRID_X_STRIDE*lane + r] : static_cast<T>(0); }")
     A("const T qd = has ? s_qd[lane] : static_cast<T>(0), qdd = has ? s_qdd[lane] : static_cast<T>(0);")
+    has_pris = any(s_ >= 3 for s_ in m_.S_index)
+    if has_pris:
+        A("const bool pris = static_cast<int>(Lc[11]) >= 3; // prismatic joint: the origin of its frame moves with q - read it off X(q) = [[E, 0], [-E r~, E]]: r~ = -E^T B")
+        A("{ T Bq[9];")
+        A("  #pragma unroll")
+        A("  for (int r = 0; r < 9; r++) { Bq[r] = has ? s_X[GRID_X_STRIDE*lane + 9 + r] : static_cast<T>(0); }")
+        A("  const T r0 = -(E[2]*Bq[1] + E[5]*Bq[4] + E[8]*Bq[7]), r1 = -(E[0]*Bq[2] + E[3]*Bq[5] + E[6]*Bq[8]), r2 = -(E[1]*Bq[0] + E[4]*Bq[3] + E[7]*Bq[6]);")
+        A("  if (pris) { Lc[12] = r0; Lc[13] = r1; Lc[14] = r2; } }")
     self.gen_add_sync(use_thread_group)
     A("// zero fill of the output record: most of its 4 n^3 entries are structural zeros of the tree (joints on different root paths)")
     A("if (active) { for (int e = lane; e < %d; e += GRID_LANES_PER_SOLVE) { so[e] = static_cast<T>(0); } }" % (4 * n ** 3))
     A("// top-down, one tree level at a time: pose of the link frame in the base frame (myR: link -> base coordinates, myp: its origin), joint axis S,")
     A("// spatial velocity v, acceleration a (with the gravity term) and Pd = v_parent x S; a joint's record [myR | myp | v | a] waits in LDS for its children")
     A("T myR[9], myp[3], S[6], v[6], a[6], Pd[6], dpar[3] = {static_cast<T>(0), static_cast<T>(0), static_cast<T>(0)}; // (dpar: origin of this joint's frame relative to its parent's, base axes)")
+    if has_pris:
+        A("T wax[3] = {static_cast<T>(0), static_cast<T>(0), static_cast<T>(0)};")
     A("#pragma unroll")
     A("for (int r = 0; r < 6; r++) { S[r] = v[r] = a[r] = Pd[r] = static_cast<T>(0); }")
     A("#pragma unroll")
@@ -762,10 +785,15 @@ def gen_idsva_so_inner_tree(self, use_thread_group=False):
     A("for (int cc = 0; cc < 3; cc++) { myR[3*r + cc] = Rp[3*r]*E[3*cc] + Rp[3*r+1]*E[3*cc+1] + Rp[3*r+2]*E[3*cc+2]; }")
     A("dpar[r] = Rp[3*r]*Lc[12] + Rp[3*r+1]*Lc[13] + Rp[3*r+2]*Lc[14]; myp[r] = pp[r] + dpar[r];")
     self.gen_add_end_control_flow()
-    A("{ const int ax = static_cast<int>(Lc[11]);")
+    A("{ const int ax = static_cast<int>(Lc[11]) % 3;" if has_pris else "{ const int ax = static_cast<int>(Lc[11]);")
     A("  #pragma unroll")
     A("  for (int r = 0; r < 3; r++) { S[r] = (ax == 0) ? myR[3*r] : ((ax == 1) ? myR[3*r+1] : myR[3*r+2]); } }")
-    A("S[3] = myp[1]*S[2] - myp[2]*S[1]; S[4] = myp[2]*S[0] - myp[0]*S[2]; S[5] = myp[0]*S[1] - myp[1]*S[0];")
+    if has_pris:
+        A("wax[0] = S[0]; wax[1] = S[1]; wax[2] = S[2]; // the joint axis in base coordinates")
+        A("if (pris) { S[3] = S[0]; S[4] = S[1]; S[5] = S[2]; S[0] = S[1] = S[2] = static_cast<T>(0); } // prismatic: [0; axis], a free vector")
+        A("else { S[3] = myp[1]*S[2] - myp[2]*S[1]; S[4] = myp[2]*S[0] - myp[0]*S[2]; S[5] = myp[0]*S[1] - myp[1]*S[0]; }")
+    else:
+        A("S[3] = myp[1]*S[2] - myp[2]*S[1]; S[4] = myp[2]*S[0] - myp[0]*S[2]; S[5] = myp[0]*S[1] - myp[1]*S[0];")
     A("grid_mxm(Pd, vp, S);")
     A("#pragma unroll")
     A("for (int r = 0; r < 6; r++) { v[r] = vp[r] + S[r]*qd; a[r] = ap[r] + Pd[r]*qd + S[r]*qdd; }")
@@ -783,7 +811,7 @@ def gen_idsva_so_inner_tree(self, use_thread_group=False):
         A("// from here on every quantity of this joint is taken about the ORIGIN OF ITS OWN FRAME (base axes): the joint axis passes through it, the link's inertia, Coriolis")
         A("// matrix and force and their subtree composites are those of a body next to the reference point - about the base origin the entries of light distal links")
         A("// are small differences of m d^2 terms, and fdsva_so multiplies them by M^-1 twice (fp32: 4e-7 of max|dM_dq| became 8e-4 of max|d2a_dtdq| on the 12-DoF tree)")
-        A("S[3] = S[4] = S[5] = static_cast<T>(0);")
+        A("if (!pris) { S[3] = S[4] = S[5] = static_cast<T>(0); }" if has_pris else "S[3] = S[4] = S[5] = static_cast<T>(0);")
         A("{ T t[6]; grid_so_motion_at(t, v, myp); v[3] = t[3]; v[4] = t[4]; v[5] = t[5]; grid_so_motion_at(t, a, myp); a[3] = t[3]; a[4] = t[4]; a[5] = t[5]; }")
         A("grid_mxm(Pd, v, S);")
     _emit_link_inertia(self, local_origin=local)
@@ -833,7 +861,8 @@ def gen_idsva_so_inner_tree(self, use_thread_group=False):
     self.gen_add_sync(use_thread_group)
     self.gen_add_end_control_flow()
     _so_emit(self, _SO_PREP, PARENT="rec[18] = static_cast<T>(par); // parent joint id (-1: base), read by the balanced main loops" +
-             ("\n    rec[3] = myp[0]; rec[4] = myp[1]; rec[5] = myp[2]; // (the linear part of S is zero about the joint's own origin: its slots carry the origin)" if local else ""))
+             ("\n    rec[3] = myp[0]; rec[4] = myp[1]; rec[5] = myp[2]; // (the linear part of S is zero about the joint's own origin: its slots carry the origin)" if local else "") +
+             ("\n    rec[0] = wax[0]; rec[1] = wax[1]; rec[2] = wax[2]; rec[19] = pris ? static_cast<T>(1) : static_cast<T>(0); // (axis and joint type: a prismatic joint's S is [0; axis])" if has_pris else ""))
     if self.tuning["so_mapping"] == "balanced":
         if self.tuning["so_loops"] == "dots":
             _so_emit_balanced_main_dots(self, tree=True, compact=False, local=local)

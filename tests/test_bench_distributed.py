@@ -47,6 +47,18 @@ def test_three_rank_harness_ragged_split():
     assert d["contiguous_cover"] is True and d["shards_sum_to_global_batch"] is True and d["solves_counted"] == 1000 * 5
 
 
+def test_eight_rank_harness_is_the_drivers_split():
+    """What the driver's N = 8 run does with the batch (16 384 -> 2 048 per GPU): eight contiguous ranges, one JSON line, the
+    slowest rank's time, and the per-rank spread (min / max over ranks) that makes a straggler visible in the first real scaling curve."""
+    d = _selftest(8, [])
+    assert d["n_gpus"] == 8 and d["scaling"] == "strong"
+    assert d["ranges"] == [[2048 * r, 2048 * (r + 1)] for r in range(8)] and d["rows"] == [2048] * 8
+    assert d["contiguous_cover"] is True and d["shards_sum_to_global_batch"] is True and d["solves_counted"] == 16384 * 5
+    assert d["max_elapsed_s"] >= 0.08  # rank 7 sleeps 80 ms
+    lo, hi = d["per_rank_ms"]["min"], d["per_rank_ms"]["max"]
+    assert 8.0 <= lo < 40.0 and hi >= 80.0 and abs(hi - 1e3 * d["max_elapsed_s"]) < 1.0  # rank 0 slept 10 ms, rank 7 80 ms
+
+
 def test_two_rank_harness_over_gloo_weak_scaling():
     d = _selftest(2, ["--scaling", "weak"])
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["distinct_shards"] is True
@@ -59,7 +71,7 @@ def test_bench_line_schema_is_complete():
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
                 "data", "config", "roofline", "cpu_baseline", "bound", "achieved", "peak", "frac", "traffic", "cores", "kind", "sample",
                 "launch_us_median", "clock_warm_ms", "ref_equiv_valu_frac", "valu_issue_frac", "traffic_source", "copy_bw_measured_GBps",
-                "end_to_end_solves_per_s", "single_thread_fp32", "single_thread_fp64", "other_scaling"):
+                "end_to_end_solves_per_s", "single_thread_fp32", "single_thread_fp64", "other_scaling", "per_rank_ms"):
         assert '"%s"' % key in src, key
 
 

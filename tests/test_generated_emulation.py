@@ -238,7 +238,7 @@ def test_emulated_error_behaviour(libs):
     assert np.isfinite(out).all()
 
 
-@pytest.mark.parametrize("name", ["iiwa14", "arm6", "chain8", "hyq", "tree12", "atlas"])
+@pytest.mark.parametrize("name", ["iiwa14", "arm6", "chain8", "hyq", "tree12", "atlas", "mixed5"])
 def test_emulated_idsva_so(name, libs, golden):
     """second-order derivatives of inverse dynamics, against the NumPy restatement of the reference's emitter
     (oracle/idsva_so_oracle.py; parity unpinned - the reference holds no vectors for it, see that module).  Serial chains run the tip-frame
@@ -334,12 +334,13 @@ def test_emulated_second_order_direct_form_on_a_chain(golden):
     assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
 
 
-@pytest.mark.parametrize("name,n", [("mixed5", 5)])
-def test_emulated_second_order_is_refused_where_it_is_not_emitted(name, n, libs):
-    """Robots with prismatic joints are outside the second-order scope: hipErrorNotSupported."""
+@pytest.mark.parametrize("name,n", [("iiwa14", 7)])
+def test_emulated_second_order_is_refused_where_it_is_not_emitted(name, n):
+    """The one-derivative-column-per-lane variant of the library carries no second-order kernels: hipErrorNotSupported.  (Robots with prismatic joints do
+    have them since round 3: the tree form carries the joint type through its records - mixed5 in test_emulated_idsva_so / test_emulated_fdsva_so.)"""
     from gridcodegenerator_amd.runtime import GridError
 
-    lib = libs(name)
+    lib = emu_library(name, max_timesteps=8, cols_per_lane=1)
     assert not lib.has_second_order
     with pytest.raises(GridError):
         lib.idsva_so_device(np.zeros((1, 3 * n), np.float32), None, 1, np.zeros((1, 4), np.float32))
@@ -347,7 +348,7 @@ def test_emulated_second_order_is_refused_where_it_is_not_emitted(name, n, libs)
         lib.fdsva_so_device(np.zeros((1, 3 * n), np.float32), 1, np.zeros((1, 4), np.float32))
 
 
-@pytest.mark.parametrize("name", ["iiwa14", "arm6", "hyq", "tree12", "atlas", "chain12"])
+@pytest.mark.parametrize("name", ["iiwa14", "arm6", "hyq", "tree12", "atlas", "chain12", "mixed5"])
 def test_emulated_fdsva_so(name, libs, golden):
     """Second half of SURVEY.md section 8(f) rank 3: second-order derivatives of forward dynamics, against the NumPy restatements of the reference's
     idsva_so + fdsva_so emitters fed by the pinned first-order oracle (parity unpinned, see oracle/fdsva_so_oracle.py)."""

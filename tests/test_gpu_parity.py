@@ -298,7 +298,7 @@ def test_non_default_generation_variants_on_gpu(tuning, torch_cuda, golden, tmp_
     lib.close()
 
 
-@pytest.mark.parametrize("name", ["iiwa14", "arm6", "chain12", "chain8", "hyq", "tree12", "atlas"])
+@pytest.mark.parametrize("name", ["iiwa14", "arm6", "chain12", "chain8", "hyq", "tree12", "atlas", "mixed5"])
 def test_idsva_so_matches_the_restated_reference_algorithm(name, torch_cuda, libs, golden):
     """SURVEY.md section 8(f) rank 3 (serial chains: tip-frame form; the quadruped, the 12-DoF tree and the 30-DoF humanoid: tree form - the humanoid's
     432 KB record goes entry by entry to global memory, GRID_SO_DIRECT): second-order inverse-dynamics derivatives on the GPU vs the NumPy restatement of the
@@ -335,16 +335,13 @@ def test_idsva_so_matches_the_restated_reference_algorithm(name, torch_cuda, lib
     assert np.array_equal(out2.cpu().numpy(), got)
 
 
-def test_second_order_is_refused_for_prismatic_joints_and_beyond_the_handles_capacity(torch_cuda, libs):
-    """Robots with prismatic joints are outside the second-order scope (hipErrorNotSupported); the 30-DoF humanoid's records are 432 KB per solve:
-    the generated init_gridData caps the second-order buffers at 1 GiB each and the C ABI rejects longer batches instead of overrunning them."""
+def test_second_order_is_refused_beyond_the_handles_capacity(torch_cuda, libs):
+    """The 30-DoF humanoid's records are 432 KB per solve: the generated init_gridData caps the second-order buffers at 1 GiB each and the C ABI rejects
+    longer batches instead of overrunning them.  (Robots with prismatic joints have second-order kernels since round 3.)"""
     from gridcodegenerator_amd.runtime import GridError
 
     torch = torch_cuda
-    lib = libs("mixed5")
-    assert not lib.has_second_order
-    with pytest.raises(GridError):
-        lib.idsva_so_device(torch.zeros((1, 15), device="cuda"), None, 1, torch.zeros((1, 4), device="cuda"))
+    assert libs("mixed5").has_second_order
     big = GridLibrary(build_library("atlas"), device=0, max_timesteps=4096)
     try:
         assert big.has_second_order
@@ -358,7 +355,7 @@ def test_second_order_is_refused_for_prismatic_joints_and_beyond_the_handles_cap
         big.close()
 
 
-@pytest.mark.parametrize("name", ["iiwa14", "arm6", "chain12", "chain8", "hyq", "tree12", "atlas"])
+@pytest.mark.parametrize("name", ["iiwa14", "arm6", "chain12", "chain8", "hyq", "tree12", "atlas", "mixed5"])
 def test_fdsva_so_matches_the_restated_reference_algorithm(name, torch_cuda, libs, golden):
     """Second half of SURVEY.md section 8(f) rank 3 (serial revolute chains): second-order forward-dynamics derivatives on the GPU vs the NumPy
     restatements of the reference's idsva_so + fdsva_so emitters fed by the pinned first-order oracle (parity unpinned)."""
@@ -467,7 +464,7 @@ def test_non_finite_solves_do_not_leak_into_their_neighbours(name, torch_cuda, l
     assert not np.isfinite(dirty[0][2]).all()
 
 
-@pytest.mark.parametrize("name,states", [("iiwa14", 2048), ("arm6", 1024), ("hyq", 2048), ("tree12", 2048), ("atlas", 128)])
+@pytest.mark.parametrize("name,states", [("iiwa14", 2048), ("arm6", 1024), ("hyq", 2048), ("tree12", 2048), ("atlas", 128), ("mixed5", 1024)])
 def test_fp32_error_tail_of_the_second_order_kernels_is_guarded(name, states, torch_cuda):
     """the second-order kernels chain the explicit-M factorisation of the first-order path with an n^4 contraction; their fp32 tail had only ever
     been looked at on 12 solves per robot (fdsva_so on the 12-DoF tree: 5.45e-5 of the 1e-4 bar).  This sweep runs idsva_so (random qdd) and fdsva_so on
