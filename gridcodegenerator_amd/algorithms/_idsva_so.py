@@ -788,12 +788,17 @@ def gen_idsva_so_inner_tree(self, use_thread_group=False):
     A("{ const int ax = static_cast<int>(Lc[11]) % 3;" if has_pris else "{ const int ax = static_cast<int>(Lc[11]);")
     A("  #pragma unroll")
     A("  for (int r = 0; r < 3; r++) { S[r] = (ax == 0) ? myR[3*r] : ((ax == 1) ? myR[3*r+1] : myR[3*r+2]); } }")
+    lin = ("S[3] = S[4] = S[5] = static_cast<T>(0);" if local else
+           "S[3] = myp[1]*S[2] - myp[2]*S[1]; S[4] = myp[2]*S[0] - myp[0]*S[2]; S[5] = myp[0]*S[1] - myp[1]*S[0];")
     if has_pris:
         A("wax[0] = S[0]; wax[1] = S[1]; wax[2] = S[2]; // the joint axis in base coordinates")
         A("if (pris) { S[3] = S[0]; S[4] = S[1]; S[5] = S[2]; S[0] = S[1] = S[2] = static_cast<T>(0); } // prismatic: [0; axis], a free vector")
-        A("else { S[3] = myp[1]*S[2] - myp[2]*S[1]; S[4] = myp[2]*S[0] - myp[0]*S[2]; S[5] = myp[0]*S[1] - myp[1]*S[0]; }")
+        A("else { %s }" % lin)
     else:
-        A("S[3] = myp[1]*S[2] - myp[2]*S[1]; S[4] = myp[2]*S[0] - myp[0]*S[2]; S[5] = myp[0]*S[1] - myp[1]*S[0];")
+        A(lin)
+    if local:
+        A("// (local origins: the parent's velocity and acceleration arrive about ITS origin and move to this joint's - the kinematics never see the far-away base origin)")
+        A("{ T t[6]; grid_so_motion_at(t, vp, dpar); vp[3] = t[3]; vp[4] = t[4]; vp[5] = t[5]; grid_so_motion_at(t, ap, dpar); ap[3] = t[3]; ap[4] = t[4]; ap[5] = t[5]; }")
     A("grid_mxm(Pd, vp, S);")
     A("#pragma unroll")
     A("for (int r = 0; r < 6; r++) { v[r] = vp[r] + S[r]*qd; a[r] = ap[r] + Pd[r]*qd + S[r]*qdd; }")
@@ -811,9 +816,7 @@ def gen_idsva_so_inner_tree(self, use_thread_group=False):
         A("// from here on every quantity of this joint is taken about the ORIGIN OF ITS OWN FRAME (base axes): the joint axis passes through it, the link's inertia, Coriolis")
         A("// matrix and force and their subtree composites are those of a body next to the reference point - about the base origin the entries of light distal links")
         A("// are small differences of m d^2 terms, and fdsva_so multiplies them by M^-1 twice (fp32: 4e-7 of max|dM_dq| became 8e-4 of max|d2a_dtdq| on the 12-DoF tree)")
-        A("if (!pris) { S[3] = S[4] = S[5] = static_cast<T>(0); }" if has_pris else "S[3] = S[4] = S[5] = static_cast<T>(0);")
-        A("{ T t[6]; grid_so_motion_at(t, v, myp); v[3] = t[3]; v[4] = t[4]; v[5] = t[5]; grid_so_motion_at(t, a, myp); a[3] = t[3]; a[4] = t[4]; a[5] = t[5]; }")
-        A("grid_mxm(Pd, v, S);")
+        A("// (S, v, a and Pd = v_parent x S were propagated about the joints' own origins already)")
     _emit_link_inertia(self, local_origin=local)
     _emit_body_terms(self)
     A("#pragma unroll")

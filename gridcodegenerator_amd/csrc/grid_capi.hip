@@ -386,20 +386,64 @@ static int host_prologue(grid_handle *h, int N) {
 #define GRID_H2D(dst, src, count) GRID_TRY(hipMemcpyAsync((dst), (src), (size_t)(count) * sizeof(T), hipMemcpyHostToDevice, s))
 #define GRID_D2H(dst, src, count) GRID_TRY(hipMemcpyAsync((dst), (src), (size_t)(count) * sizeof(T), hipMemcpyDeviceToHost, s))
 
+// Pins a caller's (pageable) host range for the duration of a call so that hipMemcpyAsync on it really is asynchronous; falls back silently
+// (ok == false) where the range cannot be registered, e.g. memory that is already pinned or mapped read-only.
+struct host_pin {
+    void *p = nullptr;
+    bool ok = false;
+    host_pin(const void *ptr, size_t bytes) {
+        if (ptr && bytes) {
+            p = const_cast<void *>(ptr);
+            ok = hipHostRegister(p, bytes, hipHostRegisterDefault) == hipSuccess;
+            if (!ok) (void)hipGetLastError();
+        }
+    }
+    ~host_pin() {
+        if (ok) (void)hipHostUnregister(p);
+    }
+};
+
+// The hot path's host entry point.  Semantics of the reference's wrapper (H2D, launch, D2H, synchronous on return; reference
+// algorithms/_forward_dynamics_gradient.py:221-245), but the batch is cut into chunks that travel on the handle's three streams: the copy
+// engines run H2D of chunk c+1 and D2H of chunk c-1 beside the kernel of chunk c.  The caller's buffers are pinned for the call
+// (hipHostRegister: ~2 us per buffer); where that is refused the call degrades to the strictly sequential form.
 template <typename T>
 static int fd_grad_host(grid_handle *h, const T *h_q_qd_u, int N, T gravity, T *h_df_du) {
     int rc = host_prologue<T>(h, N);
     if (rc || N == 0) return rc;
+    if (!h_q_qd_u || !h_df_du) return fail_msg(hipErrorInvalidValue, "null input or output pointer");
     GRID_ON_DEVICE(h);
     if ((rc = ensure_typed<T>(h))) return rc;
     const size_t n = grid::NUM_JOINTS;
     grid::gridData<T> *d = typed<T>(h).hd_data;
-    hipStream_t s = h->streams[0];
-    GRID_H2D(d->d_q_qd_u, h_q_qd_u, 3 * n * N);
-    if ((rc = fd_grad_device<T>(h, d->d_q_qd_u, 3 * (int)n, N, gravity, d->d_df_du, (void *)s))) return rc;
-    GRID_D2H(h_df_du, d->d_df_du, 2 * n * n * N);
-    GRID_TRY(hipStreamSynchronize(s));
-    return 0;
+    const int min_chunk = 2048;  // (below that a chunk's kernel is all launch latency)
+    int chunks = N / min_chunk;
+    if (chunks > 4) chunks = 4;
+    host_pin pin_in(chunks > 1 ? h_q_qd_u : nullptr, 3 * n * (size_t)N * sizeof(T)), pin_out(chunks > 1 ? h_df_du : nullptr, 2 * n * n * (size_t)N * sizeof(T));
+    if (chunks < 2 || !pin_in.ok || !pin_out.ok) {
+        hipStream_t s = h->streams[0];
+        GRID_H2D(d->d_q_qd_u, h_q_qd_u, 3 * n * N);
+        if ((rc = fd_grad_device<T>(h, d->d_q_qd_u, 3 * (int)n, N, gravity, d->d_df_du, (void *)s))) return rc;
+        GRID_D2H(h_df_du, d->d_df_du, 2 * n * n * N);
+        GRID_TRY(hipStreamSynchronize(s));
+        return 0;
+    }
+    const int per = (N + chunks - 1) / chunks;
+    for (int c = 0; c < chunks; c++) {
+        const int k0 = c * per, cnt = (k0 + per <= N) ? per : N - k0;
+        if (cnt <= 0) break;
+        hipStream_t s = h->streams[c % 3];
+        hipError_t e = hipMemcpyAsync(d->d_q_qd_u + (size_t)k0 * 3 * n, h_q_qd_u + (size_t)k0 * 3 * n, 3 * n * (size_t)cnt * sizeof(T), hipMemcpyHostToDevice, s);
+        if (e != hipSuccess) { rc = fail(e, "hipMemcpyAsync(H2D)"); break; }  // (no early return: the streams are drained below before the buffers are unpinned)
+        if ((rc = fd_grad_device<T>(h, d->d_q_qd_u + (size_t)k0 * 3 * n, 3 * (int)n, cnt, gravity, d->d_df_du + (size_t)k0 * 2 * n * n, (void *)s))) break;
+        e = hipMemcpyAsync(h_df_du + (size_t)k0 * 2 * n * n, d->d_df_du + (size_t)k0 * 2 * n * n, 2 * n * n * (size_t)cnt * sizeof(T), hipMemcpyDeviceToHost, s);
+        if (e != hipSuccess) { rc = fail(e, "hipMemcpyAsync(D2H)"); break; }
+    }
+    for (int c = 0; c < 3; c++) {  // (always drained: the caller's buffers are unpinned on return)
+        hipError_t e = hipStreamSynchronize(h->streams[c]);
+        if (e != hipSuccess && !rc) rc = fail(e, "hipStreamSynchronize");
+    }
+    return rc;
 }
 
 template <typename T>

@@ -50,6 +50,9 @@ inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
 inline hipError_t hipMalloc(void **p, size_t n) { *p = (n > ((size_t)8 << 30)) ? nullptr : calloc(1, n ? n : 1); return *p ? hipSuccess : hipErrorOutOfMemory; }
 inline hipError_t hipHostMalloc(void **p, size_t n, unsigned) { return hipMalloc(p, n); }
 inline hipError_t hipFree(void *p) { free(p); return hipSuccess; }
+enum { hipHostRegisterDefault = 0 };
+inline hipError_t hipHostRegister(void *, size_t, unsigned) { return hipSuccess; }
+inline hipError_t hipHostUnregister(void *) { return hipSuccess; }
 inline hipError_t hipHostFree(void *p) { free(p); return hipSuccess; }
 inline hipError_t hipMemcpy(void *d, const void *s, size_t n, hipMemcpyKind) { memcpy(d, s, n); return hipSuccess; }
 inline hipError_t hipMemcpyAsync(void *d, const void *s, size_t n, hipMemcpyKind, hipStream_t) { memcpy(d, s, n); return hipSuccess; }

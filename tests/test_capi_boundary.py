@@ -265,3 +265,4 @@ def test_double_precision_and_multi_device_wrappers_check_their_array_shapes():
             multi.forward_dynamics_gradient_host(np.zeros(3 * n, np.float32))
     finally:
         multi.close()
+

@@ -80,6 +80,30 @@ def test_fd_grad_matches_oracle_on_seeded_inputs(name, N, torch_cuda, libs):
     assert per_solve_err(out, ref) <= TOL
 
 
+def test_chunked_host_entry_point_gives_the_same_records_as_one_launch(torch_cuda, golden):
+    """The hot path's host entry point cuts batches of >= 4096 solves into up to four chunks that travel on the handle's three streams (H2D, kernel and D2H of
+    neighbouring chunks overlap; the caller's buffers are pinned for the call: csrc/grid_capi.hip fd_grad_host).  Ragged chunk sizes, pageable NumPy buffers,
+    bit-identical to a single device-pointer launch; and the same through the single-process multi-handle driver.  (Checked once on the CPU emulation too; it
+    is a 10-minute test there.)"""
+    from gridcodegenerator_amd.runtime import MultiGpuGrid
+
+    g = golden("iiwa14")
+    lib = GridLibrary(build_library("iiwa14"), device=0, max_timesteps=16384)
+    multi = MultiGpuGrid(lib.path, devices=[0, 0], max_timesteps=16384)
+    n = lib.n
+    try:
+        for N in (4100, 6151, 16384, 4095):  # two chunks of 2050; three chunks of 2051 / 2051 / 2049; four of 4096; one launch
+            x = np.ascontiguousarray(np.tile(np.hstack([g["q"], g["qd"], g["u"]]).astype(np.float32), (-(-N // 16), 1))[:N])
+            x[:, :n] += np.linspace(0, 0.3, N, dtype=np.float32)[:, None]
+            one = run_fd_grad(torch_cuda, lib, x)
+            out = lib.forward_dynamics_gradient_host(x)
+            assert np.isfinite(out).all() and np.array_equal(out, one), N
+            assert np.array_equal(multi.forward_dynamics_gradient_host(x), one), N
+    finally:
+        multi.close()
+        lib.close()
+
+
 def test_host_entry_point_and_grid_stride(torch_cuda, libs):
     from oracle.rbd_oracle import Oracle
 
