@@ -368,7 +368,18 @@ def main():
             for _ in range(reps):
                 lib.forward_dynamics_gradient_host(xh)
             line["end_to_end_solves_per_s"] = reps * xh.shape[0] / (time.perf_counter() - t0)
-            line["end_to_end_note"] = "grid_forward_dynamics_gradient_host: H2D + kernel + D2H per call, pageable host memory, PCIe-inclusive"
+            line["end_to_end_note"] = "grid_forward_dynamics_gradient_host: H2D + kernel + D2H per call, pageable host memory (fresh result array per call), PCIe-inclusive"
+            # the same call on page-locked buffers (grid_host_alloc): the entry point cuts the batch into chunks and overlaps H2D | kernel | D2H on three streams
+            xp, op = lib.pinned_empty(xh.shape), lib.pinned_empty((xh.shape[0], 2 * n * n))
+            xp[:] = xh
+            lib.forward_dynamics_gradient_host(xp, out=op)
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                lib.forward_dynamics_gradient_host(xp, out=op)
+            line["end_to_end_pinned_solves_per_s"] = reps * xh.shape[0] / (time.perf_counter() - t0)
+            line["end_to_end_pinned_note"] = "same call, caller's buffers from grid_host_alloc (page-locked): chunked H2D | kernel | D2H pipeline; the %.1f MB D2H at PCIe rate is the floor" % (xh.shape[0] * 2 * n * n * 4 / 1e6)
+            assert np.array_equal(op, lib.forward_dynamics_gradient_host(xh))
+            del xp, op
         if not args.no_cpu_baseline and world == 1:
             # the only place the oracle (test infrastructure) is touched: the CPU baseline leg, which also spot-checks the GPU result
             line["cpu_baseline"] = cpu_baseline(robot, r["x"])

@@ -235,8 +235,50 @@ for (int k = @K0@; k < @N@; k += @KSTEP@) {
     self.gen_add_end_function()
 
 
-def gen_fdsva_so_device(self, use_thread_group=False):
+def gen_fdsva_so_split(self):
+    """True where the host wrappers and the C ABI run fdsva_so as TWO kernels (records beyond the LDS of a CU, several base-rooted components, largest component
+    <= 22 joints - the 30-DoF humanoid): fdsva_so_prepare_kernel (lane groups: gradient, M^-1, idsva_so into the global workspace) and
+    fdsva_so_contract_kernel (one 256-thread block per solve: thread <-> entry (k, j) of a component, the dM_dq slabs staged in LDS).  The single
+    fdsva_so_kernel stays for callers that launch it themselves.  Returns (pairs per thread, largest component) or None."""
+    if not (self.gen_idsva_so_direct() and self.tuning["so_split"]):
+        return None
+    comps = self.gen_fdsva_so_components()
+    if comps is None:
+        return None
+    maxc = comps[1]
+    npairs = -(-maxc * maxc // 256)
+    if npairs * 4 * maxc > 160:
+        return None
+    return npairs, maxc
+
+
+def gen_fdsva_so_device(self, use_thread_group=False, prepare=False):
     n = self.model.n
+    if prepare:
+        self.gen_add_func_doc("First half of fdsva_so (lane-group cooperative): forward dynamics gradient, M^-1 and idsva_so at the solution; the contraction is a kernel of its own (fdsva_so_contract_kernel)",
+                              ["all lanes of the solve's lane group must call it; s_df_du holds the first-order gradient and &s_work[GRID_OFF_MINV] the dense M^-1 on return"],
+                              ["s_df_du is a pointer to LDS for the derivative of forward dynamics WRT q,qd of size 2*NUM_JOINTS*NUM_JOINTS = " + str(2 * n * n),
+                               "s_idsva_so is this solve's record in the global workspace for the 4*NUM_JOINTS^3 second derivative tensors of inverse dynamics",
+                               "s_q is the vector of joint positions", "s_qd is the vector of joint velocities", "s_u is the vector of joint control inputs",
+                               "s_work is this solve's LDS workspace of GRID_LDS_PER_SOLVE elements",
+                               "d_robotModel is the pointer to the initialized model specific helpers on the GPU (XImats, topology_helpers, etc.)",
+                               "gravity is the gravity constant", "lane is the caller's lane index inside the solve's lane group", "active is false for lane groups without a solve"], None)
+        self.gen_add_code_line("template <typename T>")
+        self.gen_add_code_line("__device__ __forceinline__")
+        self.gen_add_code_line("void fdsva_so_prepare_device(T *s_df_du, T *s_idsva_so, const T *s_q, const T *s_qd, const T *s_u, T *s_work, const robotModel<T> *d_robotModel, const T gravity, const int lane, const bool active) {", True)
+        self.gen_add_code_line("T *s_qdd = &s_work[GRID_OFF_QDD]; T *s_Minv = &s_work[GRID_OFF_MINV];")
+        assert getattr(self, "branch_frame", False) or not self.tip_frame
+        if getattr(self, "branch_frame", False):
+            self.gen_add_code_line("forward_dynamics_gradient_device<T>(s_df_du, s_q, s_qd, s_u, s_work, d_robotModel, gravity, lane);")
+            self.gen_add_code_line("s_qdd = &s_work[FD_DU_OFF_QDD];")
+        else:
+            self.gen_add_code_line("forward_dynamics_gradient_device<T>(s_df_du, s_q, s_qd, s_u, s_work, d_robotModel, gravity, lane);")
+            self.gen_add_code_line("forward_dynamics_device<T>(s_qdd, s_q, s_qd, s_u, s_work, d_robotModel, gravity, lane);")
+        self.gen_add_code_line("direct_minv_device<T>(s_Minv, s_q, s_work, d_robotModel, lane);")
+        self.gen_add_code_line("idsva_so_device<T>(s_idsva_so, s_q, s_qd, s_qdd, &s_work[GRID_OFF_X], d_robotModel, gravity, lane, active, true); // (only the component blocks of the workspace are zero-filled: what the contraction reads)")
+        self.gen_add_sync(use_thread_group)
+        self.gen_add_end_function()
+        return
     self.gen_add_func_doc("Second Order of Forward Dynamics with Spatial Vector Algebra (lane-group cooperative): forward dynamics, its gradient, M^-1, idsva_so at the solution, contraction",
                           ["all lanes of the solve's lane group must call it; s_df_du holds the first-order gradient on return (reference algorithms/_fdsva_so.py:147-156)"],
                           ["df2 is the output record of this solve: 4*NUM_JOINTS^3 values (global or LDS memory)",
@@ -388,6 +430,118 @@ def gen_fdsva_so_kernel(self, use_thread_group=False, single_call_timing=False):
     self.gen_add_end_function()
 
 
+def gen_fdsva_so_split_kernels(self, use_thread_group=False):
+    """fdsva_so_prepare_kernel + fdsva_so_contract_kernel (see gen_fdsva_so_split)."""
+    n = self.model.n
+    n2, n3 = n * n, n * n * n
+    npairs, maxc = self.gen_fdsva_so_split()
+    ld = self.minv_ld
+    stage = self.gen_fdsva_so_stage_size()
+    A = self.gen_add_code_line
+    self.gen_add_func_doc("First kernel of the two-kernel form of fdsva_so: forward dynamics gradient, M^-1 and the idsva_so tensors at qdd = FD(q, qd, u), all to global memory",
+                          ["launch like fdsva_so_kernel (FDSVA_SO_SUGGESTED_THREADS threads, FDSVA_SO_DYNAMIC_SHARED_MEM_COUNT*sizeof(T) bytes of dynamic LDS); then fdsva_so_contract_kernel"],
+                          ["d_idsva_so receives the 4*NUM_JOINTS^3 idsva_so tensors of every solve", "d_df_du receives df/du (2*NUM_JOINTS^2 values per solve, [col*n + row])",
+                           "d_Minv receives the dense symmetric M^-1 (NUM_JOINTS^2 values per solve)",
+                           "d_q_qd_u is the vector of joint positions, velocities, and input torques", "stride_q_qd_u is the stride between each q, qd, u",
+                           "d_robotModel is the pointer to the initialized model specific helpers on the GPU (XImats, topology_helpers, etc.)", "gravity is the gravity constant",
+                           "num_timesteps is the length of the trajectory points we need to compute over"], None)
+    A("template <typename T>")
+    A("__global__ GRID_LAUNCH_BOUNDS")
+    A("void fdsva_so_prepare_kernel(T *d_idsva_so, T *d_df_du, T *d_Minv, const T *d_q_qd_u, const int stride_q_qd_u, const robotModel<T> *d_robotModel, const T gravity, const int NUM_TIMESTEPS) {", True)
+    self.gen_kernel_prologue("FDSVA_SO_LDS_PER_SOLVE", "FDSVA_SO_MAX_SOLVES_PER_BLOCK")
+    self.gen_add_code_lines(["T *s_q_qd_u = &s_mem[GRID_OFF_IN]; T *s_q = s_q_qd_u; T *s_qd = &s_q_qd_u[%d]; T *s_u = &s_q_qd_u[%d];" % (n, 2 * n),
+                             "T *s_df_du = &s_out_all[grp*%d];" % stage])
+    self.gen_add_parallel_loop("k", "NUM_TIMESTEPS", use_thread_group, block_level=True)
+    self.gen_kernel_load_inputs("q_qd_u", "stride_q_qd_u", 3 * n, use_thread_group)
+    A("fdsva_so_prepare_device<T>(s_df_du, &d_idsva_so[static_cast<size_t>(kc)*%d], s_q, s_qd, s_u, s_mem, d_robotModel, gravity, lane, valid);" % (4 * n3))
+    A("if (valid) { // df/du and the dense M^-1 of this solve: what the contraction kernel reads besides the tensors", True)
+    A("const T *s_Minv = &s_mem[GRID_OFF_MINV];")
+    A("for (int e = lane; e < %d; e += GRID_LANES_PER_SOLVE) { d_df_du[static_cast<size_t>(k)*%d + e] = s_df_du[e]; }" % (2 * n2, 2 * n2))
+    A("for (int e = lane; e < %d; e += GRID_LANES_PER_SOLVE) { d_Minv[static_cast<size_t>(k)*%d + e] = s_Minv[(e / %d)*%d + (e %% %d)]; }" % (n2, n2, n, ld, n))
+    self.gen_add_end_control_flow()
+    self.gen_add_sync(use_thread_group)
+    self.gen_add_end_control_flow()
+    self.gen_add_end_function()
+
+    comps = [(r, len(self.model.subtree[r])) for r in self.model.roots]
+    C2 = maxc * maxc
+    self.gen_add_func_doc("Second kernel of the two-kernel form of fdsva_so: the contraction of the idsva_so tensors with M^-1 and df/du (reference algorithms/_fdsva_so.py:52-81)",
+                          ["one block of FDSVA_SO_CONTRACT_THREADS = 256 threads per solve (grid-stride over the batch), FDSVA_SO_CONTRACT_LDS*sizeof(T) bytes of dynamic LDS",
+                           "block diagonal over the base-rooted components (a fixed base decouples them): thread <-> entry (k, j) of a component; per L the slab dM_dq[L] of the component",
+                           "is staged in LDS, T1 = dM_dq[L] x [df/dq | df/dqd | M^-1] by every thread for its entry, the transposed term of inner_dq through LDS, and the entry's",
+                           "four inner values go into 4 x (component size) accumulators out_x[i][k][j] = -sum_L Minv[L][i] inner_x[L][k][j]; the record is zero-filled first"],
+                          ["d_df2 is the output: 4*NUM_JOINTS^3 values per solve, [d2a_dqdq | d2a_dvdv | d2a_dvdq | d2a_dtdq]",
+                           "d_idsva_so, d_df_du, d_Minv are what fdsva_so_prepare_kernel left behind", "num_timesteps is the length of the trajectory points we need to compute over"], None)
+    A("const int FDSVA_SO_CONTRACT_THREADS = 256;")
+    A("const int FDSVA_SO_CONTRACT_LDS = %d; // df/dq | df/dqd | M^-1 | dM_dq slab | T1 of one component (%d x %d each)" % (5 * C2, maxc, maxc))
+    A("template <typename T>")
+    A("__global__ __launch_bounds__(256)")
+    A("void fdsva_so_contract_kernel(T *d_df2, const T *d_idsva_so, const T *d_df_du, const T *d_Minv, const int NUM_TIMESTEPS) {", True)
+    A("T *s_Fq = reinterpret_cast<T *>(grid_smem_raw), *s_Fv = s_Fq + %d, *s_Mi = s_Fv + %d, *s_dM = s_Mi + %d, *s_A = s_dM + %d;" % (C2, C2, C2, C2))
+    A("const int tid = threadIdx.x + threadIdx.y*blockDim.x;")
+    A("for (int k0 = blockIdx.x + blockIdx.y*gridDim.x; k0 < NUM_TIMESTEPS; k0 += gridDim.x*gridDim.y) {", True)
+    A("const T *so = &d_idsva_so[static_cast<size_t>(k0)*%d]; const T *dfdu = &d_df_du[static_cast<size_t>(k0)*%d]; const T *Minv = &d_Minv[static_cast<size_t>(k0)*%d];" % (4 * n3, 2 * n2, n2))
+    A("T *df2 = &d_df2[static_cast<size_t>(k0)*%d];" % (4 * n3))
+    A("{ const T z4[4] = {static_cast<T>(0), static_cast<T>(0), static_cast<T>(0), static_cast<T>(0)}; // entries that couple different components are exact zeros")
+    A("  for (int e = tid; e < %d; e += 256) { grid_store4(df2 + 4*e, z4); } }" % n3)
+    A("__syncthreads(); // (the block's zero stores are complete before any thread overwrites an entry)")
+    for (c0, cs) in comps:
+        A("{ // base-rooted component: joints %d .. %d" % (c0, c0 + cs - 1), True)
+        A("for (int e = tid; e < %d; e += 256) { const int p = e / %d, j = e %% %d; // [p][j]: df/dq, df/dqd and M^-1 of the component" % (cs * cs, cs, cs))
+        A("  s_Fq[e] = dfdu[(%d + j)*%d + %d + p]; s_Fv[e] = dfdu[(%d + %d + j)*%d + %d + p]; s_Mi[e] = Minv[(%d + j)*%d + %d + p]; }" % (c0, n, c0, n, c0, n, c0, c0, n, c0))
+        np_c = -(-cs * cs // 256)
+        nsl = -(-cs * cs // 256)  # slab elements per thread
+        A("#pragma unroll 1")
+        A("for (int rnd = 0; rnd < %d; rnd++) { // entries (k, j) of the component, 256 per round (the accumulators of one entry per thread: %d registers)" % (np_c, 4 * cs), True)
+        if np_c == 1:
+            A("const bool ok = tid < %d; const int kk = ok ? tid / %d : 0, jj = ok ? tid %% %d : 0; (void)rnd;" % (cs * cs, cs, cs))
+        else:
+            # an entry and its transpose (k, j) <-> (j, k) must be in the SAME round (inner_dq takes T1[j][k] from the thread of the transposed entry):
+            # round 0 = the 16 x 16 block k, j < 16, round 1 = the rest (rows k >= 16, then the columns j >= 16 of the rows k < 16)
+            assert np_c == 2 and cs * cs - 256 <= 256
+            A("bool ok; int kk, jj;")
+            A("if (rnd == 0) { ok = true; kk = tid >> 4; jj = tid & 15; }")
+            A("else if (tid < %d) { ok = true; kk = 16 + tid / %d; jj = tid %% %d; }" % ((cs - 16) * cs, cs, cs))
+            A("else { const int e1 = tid - %d; ok = e1 < %d; kk = ok ? e1 / %d : 0; jj = ok ? 16 + e1 %% %d : 0; }" % ((cs - 16) * cs, 16 * (cs - 16), cs - 16, cs - 16))
+        A("T oq[%d], ov[%d], oc[%d], ot[%d];" % (cs, cs, cs, cs))
+        A("#pragma unroll")
+        A("for (int i = 0; i < %d; i++) { oq[i] = ov[i] = oc[i] = ot[i] = static_cast<T>(0); }" % cs)
+        A("// software pipeline: the slab dM_dq[L+1] and this entry's tensor values at L+1 are in flight while step L computes")
+        A("T nsl[%d], nq, nc, nv;" % nsl)
+        slab = lambda Lv: "; ".join("nsl[%d] = (tid + %d < %d) ? so[%d + ((%d + %s)*%d + %d + (tid + %d) / %d)*%d + %d + (tid + %d) %% %d] : static_cast<T>(0)" % (r, 256 * r, cs * cs, 3 * n3, c0, Lv, n, c0, 256 * r, cs, n, c0, 256 * r, cs) for r in range(nsl))
+        vals = lambda Lv: "{ const int g = ((%d + %s)*%d + %d + kk)*%d + %d + jj; nq = so[g]; nc = so[%d + g]; nv = so[%d + g]; }" % (c0, Lv, n, c0, n, c0, 2 * n3, n3)
+        A(slab("0") + ";")
+        A(vals("0"))
+        A("#pragma unroll 1")
+        A("for (int L = 0; L < %d; L++) {" % cs, True)
+        A("__syncthreads(); // (the previous slab and T1 are no longer read)")
+        for r in range(nsl):
+            A("if (tid + %d < %d) { s_dM[tid + %d] = nsl[%d]; } // dM_dq[L][k][p] of the component" % (256 * r, cs * cs, 256 * r, r))
+        A("const T cq = nq, cc = nc, cv = nv;")
+        A("__syncthreads();")
+        A("{ const int Ln = (L + 1 < %d) ? L + 1 : L;" % cs)
+        A("  " + slab("Ln") + ";")
+        A("  " + vals("Ln") + " }")
+        A("T aq = static_cast<T>(0), av = static_cast<T>(0), am = static_cast<T>(0);")
+        A("#pragma unroll")
+        A("for (int p = 0; p < %d; p++) { const T mk = s_dM[kk*%d + p]; aq += mk*s_Fq[p*%d + jj]; av += mk*s_Fv[p*%d + jj]; am += mk*s_Mi[p*%d + jj]; }" % (cs, cs, cs, cs, cs))
+        A("if (ok) { s_A[kk*%d + jj] = aq; }" % cs)
+        A("__syncthreads();")
+        A("const T iq = aq + s_A[jj*%d + kk] + cq, ic = av + cc, it = am, iv = cv; // inner_dq, inner_cross, inner_tau, d2tau_dvdv at (L, k, j)" % cs)
+        A("#pragma unroll")
+        A("for (int i = 0; i < %d; i++) { const T mi = s_Mi[L*%d + i]; oq[i] += mi*iq; oc[i] += mi*ic; ov[i] += mi*iv; ot[i] += mi*it; }" % (cs, cs))
+        self.gen_add_end_control_flow()
+        A("if (ok) {", True)
+        A("#pragma unroll")
+        A("for (int i = 0; i < %d; i++) { const int e = ((%d + i)*%d + %d + kk)*%d + %d + jj; df2[e] = -oq[i]; df2[%d + e] = -ov[i]; df2[%d + e] = -oc[i]; df2[%d + e] = -ot[i]; }" % (cs, c0, n, c0, n, c0, n3, 2 * n3, 3 * n3))
+        self.gen_add_end_control_flow()
+        self.gen_add_end_control_flow()
+        A("__syncthreads();")
+        self.gen_add_end_control_flow()
+    self.gen_add_end_control_flow()
+    self.gen_add_end_function()
+
+
 def gen_fdsva_so_host(self, mode=0):
     single_call_timing = mode == 1
     compute_only = mode == 2
@@ -418,8 +572,15 @@ def gen_fdsva_so_host(self, mode=0):
     self.gen_add_code_line("// then call the kernel")
     if single_call_timing:
         self.gen_add_code_line("struct timespec start, end; clock_gettime(CLOCK_MONOTONIC,&start);")
-    self.gen_add_code_lines(["hipLaunchKernelGGL((" + kern + "),block_dimms,thread_dimms,grid_lds_bytes<T>(thread_dimms, FDSVA_SO_LDS_PER_SOLVE, FDSVA_SO_STAGE_PER_SOLVE, FDSVA_SO_MAX_SOLVES_PER_BLOCK),0,hd_data->d_df2," + ("hd_data->d_idsva_so," if self.gen_idsva_so_direct() else "") + "hd_data->d_q_qd_u,stride_q_qd_u,d_robotModel,gravity,num_timesteps);",
-                             "gpuErrchk(hipGetLastError()); gpuErrchk(hipDeviceSynchronize());"])
+    if self.gen_fdsva_so_split() is not None and not single_call_timing:
+        self.gen_add_code_lines(["// two kernels (GRID_SO_SPLIT): gradient, M^-1 and the idsva_so tensors by lane groups, then the contraction with one block per solve",
+                                 "hipLaunchKernelGGL((fdsva_so_prepare_kernel<T>),block_dimms,thread_dimms,grid_lds_bytes<T>(thread_dimms, FDSVA_SO_LDS_PER_SOLVE, FDSVA_SO_STAGE_PER_SOLVE, FDSVA_SO_MAX_SOLVES_PER_BLOCK),0,hd_data->d_idsva_so,hd_data->d_df_du,hd_data->d_Minv,hd_data->d_q_qd_u,stride_q_qd_u,d_robotModel,gravity,num_timesteps);",
+                                 "gpuErrchk(hipGetLastError());",
+                                 "hipLaunchKernelGGL((fdsva_so_contract_kernel<T>),dim3(num_timesteps < 4096 ? (num_timesteps > 0 ? num_timesteps : 1) : 4096),dim3(FDSVA_SO_CONTRACT_THREADS),FDSVA_SO_CONTRACT_LDS*sizeof(T),0,hd_data->d_df2,hd_data->d_idsva_so,hd_data->d_df_du,hd_data->d_Minv,num_timesteps);",
+                                 "gpuErrchk(hipGetLastError()); gpuErrchk(hipDeviceSynchronize());"])
+    else:
+        self.gen_add_code_lines(["hipLaunchKernelGGL((" + kern + "),block_dimms,thread_dimms,grid_lds_bytes<T>(thread_dimms, FDSVA_SO_LDS_PER_SOLVE, FDSVA_SO_STAGE_PER_SOLVE, FDSVA_SO_MAX_SOLVES_PER_BLOCK),0,hd_data->d_df2," + ("hd_data->d_idsva_so," if self.gen_idsva_so_direct() else "") + "hd_data->d_q_qd_u,stride_q_qd_u,d_robotModel,gravity,num_timesteps);",
+                                 "gpuErrchk(hipGetLastError()); gpuErrchk(hipDeviceSynchronize());"])
     if single_call_timing:
         self.gen_add_code_line("clock_gettime(CLOCK_MONOTONIC,&end);")
     if not compute_only:
@@ -438,6 +599,9 @@ def gen_fdsva_so(self, use_thread_group=False):
     self.gen_fdsva_so_device(use_thread_group)
     if self.gen_fdsva_so_fused_layout() is not None:
         self.gen_fdsva_so_fused_device(use_thread_group)
+    if self.gen_fdsva_so_split() is not None:
+        self.gen_fdsva_so_device(use_thread_group, prepare=True)
+        self.gen_fdsva_so_split_kernels(use_thread_group)
     self.gen_fdsva_so_kernel(use_thread_group, True)
     self.gen_fdsva_so_kernel(use_thread_group, False)
     for mode in (0, 1, 2):

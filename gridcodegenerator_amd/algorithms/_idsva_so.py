@@ -116,7 +116,8 @@ def gen_idsva_so_tree_tables(self):
 
 
 def gen_idsva_so_inner_function_call(self, use_thread_group=False, use_qdd_input=False, updated_var_names=None, compact=False):
-    self.gen_add_code_line("idsva_so_inner" + ("_compact" if compact else "") + "<T>(so, s_qd, s_qdd, s_X, d_robotModel, gravity, lane, active);")
+    zb = ", blocks_only" if (self.gen_idsva_so_mode() == "tree" and len(self.model.roots) > 1) else ""
+    self.gen_add_code_line("idsva_so_inner" + ("_compact" if compact else "") + "<T>(so, s_qd, s_qdd, s_X, d_robotModel, gravity, lane, active" + zb + ");")
 
 
 def gen_idsva_so_inner(self, use_thread_group=False, use_qdd_input=False, compact=False):
@@ -595,10 +596,12 @@ def _so_inner_header(self, compact=False):
                           [("so is the compact staging record of this solve (IDSVA_SO_STAGE_PER_SOLVE values)" if compact else "so is the output record of this solve (4*NUM_JOINTS^3 values)"), "s_qd is the vector of joint velocities in LDS",
                            "s_qdd is the vector of joint accelerations in LDS", "s_X is this solve's scratch: compact X(q) storage on entry; it is overwritten by the per-joint records",
                            "d_robotModel is the pointer to the initialized model specific helpers on the GPU", "gravity is the gravity constant",
-                           "lane is the caller's lane index inside the solve's lane group", "active is false for lane groups without a solve (they compute but do not store)"], None)
+                           "lane is the caller's lane index inside the solve's lane group", "active is false for lane groups without a solve (they compute but do not store)"] +
+                          (["blocks_only (robots with several base-rooted components): zero-fill only the entries whose three indices lie in ONE component - the others are never written"] if (self.gen_idsva_so_mode() == "tree" and len(self.model.roots) > 1) else []), None)
     self.gen_add_code_line("template <typename T>")
     self.gen_add_code_line("__device__ __forceinline__")
-    self.gen_add_code_line("void idsva_so_inner" + ("_compact" if compact else "") + "(T *__restrict__ so, const T *__restrict__ s_qd, const T *__restrict__ s_qdd, T *__restrict__ s_X, const robotModel<T> *d_robotModel, const T gravity, const int lane, const bool active) {", True)
+    zb = ", const bool blocks_only = false" if (self.gen_idsva_so_mode() == "tree" and len(self.model.roots) > 1) else ""
+    self.gen_add_code_line("void idsva_so_inner" + ("_compact" if compact else "") + "(T *__restrict__ so, const T *__restrict__ s_qd, const T *__restrict__ s_qdd, T *__restrict__ s_X, const robotModel<T> *d_robotModel, const T gravity, const int lane, const bool active" + zb + ") {", True)
 
 
 def gen_idsva_so_inner_chain(self, use_thread_group=False, compact=False):
@@ -751,7 +754,17 @@ def gen_idsva_so_inner_tree(self, use_thread_group=False):
         A("  if (pris) { Lc[12] = r0; Lc[13] = r1; Lc[14] = r2; } }")
     self.gen_add_sync(use_thread_group)
     A("// zero fill of the output record: most of its 4 n^3 entries are structural zeros of the tree (joints on different root paths)")
-    A("if (active) { for (int e = lane; e < %d; e += GRID_LANES_PER_SOLVE) { so[e] = static_cast<T>(0); } }" % (4 * n ** 3))
+    if len(m_.roots) > 1:
+        A("if (active && blocks_only) { // (what fdsva_so_contract_kernel reads: the blocks of the base-rooted components; rows of `size` contiguous entries)", True)
+        for r_ in m_.roots:
+            c0, cs = r_, len(m_.subtree[r_])
+            A("for (int r = lane; r < %d; r += GRID_LANES_PER_SOLVE) { const int t = r / %d, ia = r %% %d; T *row = &so[t*%d + ((%d + ia / %d)*%d + %d + ia %% %d)*%d + %d];" % (4 * cs * cs, cs * cs, cs * cs, n ** 3, c0, cs, n, c0, cs, n, c0))
+            A("  #pragma unroll")
+            A("  for (int b = 0; b < %d; b++) { row[b] = static_cast<T>(0); } }" % cs)
+        self.gen_add_end_control_flow()
+        A("else if (active) { for (int e = lane; e < %d; e += GRID_LANES_PER_SOLVE) { so[e] = static_cast<T>(0); } }" % (4 * n ** 3))
+    else:
+        A("if (active) { for (int e = lane; e < %d; e += GRID_LANES_PER_SOLVE) { so[e] = static_cast<T>(0); } }" % (4 * n ** 3))
     A("// top-down, one tree level at a time: pose of the link frame in the base frame (myR: link -> base coordinates, myp: its origin), joint axis S,")
     A("// spatial velocity v, acceleration a (with the gravity term) and Pd = v_parent x S; a joint's record [myR | myp | v | a] waits in LDS for its children")
     A("T myR[9], myp[3], S[6], v[6], a[6], Pd[6], dpar[3] = {static_cast<T>(0), static_cast<T>(0), static_cast<T>(0)}; // (dpar: origin of this joint's frame relative to its parent's, base axes)")
@@ -908,7 +921,8 @@ def gen_idsva_so_device(self, use_thread_group=False, use_qdd_input=False, compa
     self.gen_add_code_line("template <typename T>")
     self.gen_add_code_line("__device__ __forceinline__")
     self.gen_add_code_line("void idsva_so_device" + ("_compact" if compact else "") + "(T *so, const T *s_q, const T *s_qd, " + ("const T *s_qdd, " if use_qdd_input else "") +
-                           "T *s_scratch, const robotModel<T> *d_robotModel, const T gravity, const int lane, const bool active) {", True)
+                           "T *s_scratch, const robotModel<T> *d_robotModel, const T gravity, const int lane, const bool active" +
+                           (", const bool blocks_only = false" if (self.gen_idsva_so_mode() == "tree" and len(self.model.roots) > 1) else "") + ") {", True)
     self.gen_add_code_line("T *s_X = s_scratch;")
     if not use_qdd_input:
         self.gen_add_code_line("T *s_qdd = &s_scratch[%d];" % (self.gen_idsva_so_rec() * n))

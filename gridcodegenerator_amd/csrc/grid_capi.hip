@@ -357,7 +357,16 @@ static int fdsva_so_device(grid_handle *h, const T *d_q_qd_u, int stride, int N,
         std::lock_guard<std::mutex> lock(h->alloc_lock);
         if (!h->so_done) GRID_TRY(hipEventCreateWithFlags(&h->so_done, hipEventDisableTiming));
         if (h->so_pending) GRID_TRY(hipStreamWaitEvent((hipStream_t)stream, h->so_done, 0));  // (the previous launch may be on another stream)
+#if GRID_SO_SPLIT
+        // two kernels: gradient, M^-1 and the tensors by lane groups into the handle's buffers, then the contraction with one block per solve
+        hipLaunchKernelGGL((grid_so::fdsva_so_prepare_kernel<T>), c.grid, c.block, c.lds, (hipStream_t)stream, typed<T>(h).hd_data->d_idsva_so, typed<T>(h).hd_data->d_df_du,
+                           typed<T>(h).hd_data->d_Minv, d_q_qd_u, stride, reinterpret_cast<const grid_so::robotModel<T> *>(typed<T>(h).d_robotModel), gravity, N);
+        GRID_TRY(hipGetLastError());
+        hipLaunchKernelGGL((grid_so::fdsva_so_contract_kernel<T>), dim3(N < 4096 ? N : 4096), dim3(grid_so::FDSVA_SO_CONTRACT_THREADS), (size_t)grid_so::FDSVA_SO_CONTRACT_LDS * sizeof(T),
+                           (hipStream_t)stream, d_df2, typed<T>(h).hd_data->d_idsva_so, typed<T>(h).hd_data->d_df_du, typed<T>(h).hd_data->d_Minv, N);
+#else
         hipLaunchKernelGGL((grid_so::fdsva_so_kernel<T>), c.grid, c.block, c.lds, (hipStream_t)stream, d_df2, typed<T>(h).hd_data->d_idsva_so, d_q_qd_u, stride, reinterpret_cast<const grid_so::robotModel<T> *>(typed<T>(h).d_robotModel), gravity, N);
+#endif
         GRID_TRY(hipGetLastError());
         GRID_TRY(hipEventRecord(h->so_done, (hipStream_t)stream));
         h->so_pending = true;
@@ -386,27 +395,22 @@ static int host_prologue(grid_handle *h, int N) {
 #define GRID_H2D(dst, src, count) GRID_TRY(hipMemcpyAsync((dst), (src), (size_t)(count) * sizeof(T), hipMemcpyHostToDevice, s))
 #define GRID_D2H(dst, src, count) GRID_TRY(hipMemcpyAsync((dst), (src), (size_t)(count) * sizeof(T), hipMemcpyDeviceToHost, s))
 
-// Pins a caller's (pageable) host range for the duration of a call so that hipMemcpyAsync on it really is asynchronous; falls back silently
-// (ok == false) where the range cannot be registered, e.g. memory that is already pinned or mapped read-only.
-struct host_pin {
-    void *p = nullptr;
-    bool ok = false;
-    host_pin(const void *ptr, size_t bytes) {
-        if (ptr && bytes) {
-            p = const_cast<void *>(ptr);
-            ok = hipHostRegister(p, bytes, hipHostRegisterDefault) == hipSuccess;
-            if (!ok) (void)hipGetLastError();
-        }
+// true where `ptr` is page-locked host memory the GPU's copy engines can reach directly (hipHostMalloc / grid_host_alloc / hipHostRegister): only then is
+// hipMemcpyAsync asynchronous.  (Pinning a caller's pageable buffer for one call was tried: hipHostRegister of a freshly allocated 6.4 MB result buffer costs more
+// than the overlap gains - 64 instead of 77 M solves/s end to end.)
+static bool is_pinned_host(const void *ptr) {
+    hipPointerAttribute_t a;
+    if (hipPointerGetAttributes(&a, ptr) != hipSuccess) {
+        (void)hipGetLastError();
+        return false;
     }
-    ~host_pin() {
-        if (ok) (void)hipHostUnregister(p);
-    }
-};
+    return a.type == hipMemoryTypeHost;
+}
 
 // The hot path's host entry point.  Semantics of the reference's wrapper (H2D, launch, D2H, synchronous on return; reference
-// algorithms/_forward_dynamics_gradient.py:221-245), but the batch is cut into chunks that travel on the handle's three streams: the copy
-// engines run H2D of chunk c+1 and D2H of chunk c-1 beside the kernel of chunk c.  The caller's buffers are pinned for the call
-// (hipHostRegister: ~2 us per buffer); where that is refused the call degrades to the strictly sequential form.
+// algorithms/_forward_dynamics_gradient.py:221-245).  Where BOTH of the caller's buffers are page-locked (grid_host_alloc) the batch is cut into chunks that
+// travel on the handle's three streams: the copy engines run H2D of chunk c+1 and D2H of chunk c-1 beside the kernel of chunk c.  Pageable buffers take the
+// strictly sequential form (hipMemcpyAsync blocks on them anyway).
 template <typename T>
 static int fd_grad_host(grid_handle *h, const T *h_q_qd_u, int N, T gravity, T *h_df_du) {
     int rc = host_prologue<T>(h, N);
@@ -419,8 +423,7 @@ static int fd_grad_host(grid_handle *h, const T *h_q_qd_u, int N, T gravity, T *
     const int min_chunk = 2048;  // (below that a chunk's kernel is all launch latency)
     int chunks = N / min_chunk;
     if (chunks > 4) chunks = 4;
-    host_pin pin_in(chunks > 1 ? h_q_qd_u : nullptr, 3 * n * (size_t)N * sizeof(T)), pin_out(chunks > 1 ? h_df_du : nullptr, 2 * n * n * (size_t)N * sizeof(T));
-    if (chunks < 2 || !pin_in.ok || !pin_out.ok) {
+    if (chunks < 2 || !is_pinned_host(h_q_qd_u) || !is_pinned_host(h_df_du)) {
         hipStream_t s = h->streams[0];
         GRID_H2D(d->d_q_qd_u, h_q_qd_u, 3 * n * N);
         if ((rc = fd_grad_device<T>(h, d->d_q_qd_u, 3 * (int)n, N, gravity, d->d_df_du, (void *)s))) return rc;
@@ -434,12 +437,12 @@ static int fd_grad_host(grid_handle *h, const T *h_q_qd_u, int N, T gravity, T *
         if (cnt <= 0) break;
         hipStream_t s = h->streams[c % 3];
         hipError_t e = hipMemcpyAsync(d->d_q_qd_u + (size_t)k0 * 3 * n, h_q_qd_u + (size_t)k0 * 3 * n, 3 * n * (size_t)cnt * sizeof(T), hipMemcpyHostToDevice, s);
-        if (e != hipSuccess) { rc = fail(e, "hipMemcpyAsync(H2D)"); break; }  // (no early return: the streams are drained below before the buffers are unpinned)
+        if (e != hipSuccess) { rc = fail(e, "hipMemcpyAsync(H2D)"); break; }  // (no early return: the streams are drained below)
         if ((rc = fd_grad_device<T>(h, d->d_q_qd_u + (size_t)k0 * 3 * n, 3 * (int)n, cnt, gravity, d->d_df_du + (size_t)k0 * 2 * n * n, (void *)s))) break;
         e = hipMemcpyAsync(h_df_du + (size_t)k0 * 2 * n * n, d->d_df_du + (size_t)k0 * 2 * n * n, 2 * n * n * (size_t)cnt * sizeof(T), hipMemcpyDeviceToHost, s);
         if (e != hipSuccess) { rc = fail(e, "hipMemcpyAsync(D2H)"); break; }
     }
-    for (int c = 0; c < 3; c++) {  // (always drained: the caller's buffers are unpinned on return)
+    for (int c = 0; c < 3; c++) {  // (always drained: the call is synchronous on return)
         hipError_t e = hipStreamSynchronize(h->streams[c]);
         if (e != hipSuccess && !rc) rc = fail(e, "hipStreamSynchronize");
     }
@@ -648,6 +651,17 @@ int grid_close(grid_handle *h) {
 }
 
 int grid_device(const grid_handle *h) { return h ? h->device : -1; }
+
+int grid_host_alloc(size_t bytes, void **out) {
+    if (!out) return fail_msg(hipErrorInvalidValue, "grid_host_alloc: null result pointer");
+    *out = nullptr;
+    GRID_TRY(hipHostMalloc(out, bytes ? bytes : 1, hipHostMallocDefault));
+    return 0;
+}
+int grid_host_free(void *p) {
+    if (p) GRID_TRY(hipHostFree(p));
+    return 0;
+}
 
 int grid_set_launch_dims(grid_handle *h, int blocks, int threads) {
     if (!h) return (int)hipErrorInvalidValue;

@@ -119,6 +119,20 @@ class GridLibrary:
         self._check(L.grid_init(ctypes.c_int(device), ctypes.c_int(max_timesteps), ctypes.byref(self.handle)))
         self.max_timesteps = max_timesteps
 
+    def pinned_empty(self, shape, dtype=np.float32):
+        """A NumPy array in page-locked host memory (grid_host_alloc): with such buffers forward_dynamics_gradient_host(..., out=...) overlaps its copies
+        with the kernel.  The memory is released when the array (and every view of it) is gone."""
+        import weakref
+
+        dtype = np.dtype(dtype)
+        count = int(np.prod(shape))
+        p = ctypes.c_void_p()
+        self._check(self.lib.grid_host_alloc(ctypes.c_size_t(max(1, count * dtype.itemsize)), ctypes.byref(p)))
+        buf = (ctypes.c_char * max(1, count * dtype.itemsize)).from_address(p.value)
+        arr = np.frombuffer(buf, dtype=dtype, count=count).reshape(shape)
+        weakref.finalize(buf, self.lib.grid_host_free, ctypes.c_void_p(p.value))
+        return arr
+
     def second_order_capacity(self, f64=False):
         """Solves per call the second-order entry points accept on this handle (their buffers are capped at 1 GiB each)."""
         return self.lib.grid_second_order_capacity(self.handle, ctypes.c_int(1 if f64 else 0))
@@ -142,10 +156,15 @@ class GridLibrary:
             raise ValueError("%s must have shape (N, %s)" % (what, cols))
         return x
 
-    def forward_dynamics_gradient_host(self, q_qd_u, gravity=9.81):
-        x = self._host_in(q_qd_u, 3 * self.n, "q_qd_u")
+    def forward_dynamics_gradient_host(self, q_qd_u, gravity=9.81, out=None):
+        """out: optional (N, 2n^2) float32 result array (e.g. from pinned_empty(): with page-locked input AND output the C entry point pipelines its copies)."""
+        x = q_qd_u if (isinstance(q_qd_u, np.ndarray) and q_qd_u.dtype == np.float32 and q_qd_u.flags["C_CONTIGUOUS"] and q_qd_u.ndim == 2 and q_qd_u.shape[1] == 3 * self.n) \
+            else self._host_in(q_qd_u, 3 * self.n, "q_qd_u")  # (no copy of an array that already has the right layout: a copy would leave page-locked memory)
         N = x.shape[0]
-        out = np.empty((N, 2 * self.n * self.n), dtype=np.float32)
+        if out is None:
+            out = np.empty((N, 2 * self.n * self.n), dtype=np.float32)
+        elif out.dtype != np.float32 or out.shape != (N, 2 * self.n * self.n) or not out.flags["C_CONTIGUOUS"]:
+            raise ValueError("out must be a C-contiguous float32 array of shape (N, 2n^2)")
         self._check(self.lib.grid_forward_dynamics_gradient_host(self.handle, _ptr(x), ctypes.c_int(N), ctypes.c_float(gravity), _ptr(out)))
         return out
 

@@ -26,6 +26,7 @@
 #ifndef GRID_CAPI_H
 #define GRID_CAPI_H
 
+#include <stddef.h>
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -48,6 +49,11 @@ int grid_init(int device, int max_timesteps, grid_handle **out);
 int grid_close(grid_handle *h);
 /* device the handle was created on (-1 for NULL) */
 int grid_device(const grid_handle *h);
+/* Page-locked host buffers (hipHostMalloc / hipHostFree).  Replaces the pinned h_* members of gridData that the reference's callers fill and read
+ * (reference GRiDCodeGenerator.py:160-213 allocates them with malloc; ours with hipHostMalloc).  grid_forward_dynamics_gradient_host overlaps its
+ * copies with the kernel when BOTH of its buffers come from here (or are otherwise page-locked); pageable buffers take the sequential form. */
+int grid_host_alloc(size_t bytes, void **out);
+int grid_host_free(void *p);
 /* solves per call the second-order entry points accept on this handle: min(max_timesteps, 1 GiB / record) - the generated init_gridData<T>()
  * caps the d_idsva_so / d_df2 buffers (4 n^3 values per solve; grid_so_max_timesteps<T>() of the generated header).  f64 != 0: the _f64 forms */
 int grid_second_order_capacity(const grid_handle *h, int f64);

@@ -50,9 +50,10 @@ inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
 inline hipError_t hipMalloc(void **p, size_t n) { *p = (n > ((size_t)8 << 30)) ? nullptr : calloc(1, n ? n : 1); return *p ? hipSuccess : hipErrorOutOfMemory; }
 inline hipError_t hipHostMalloc(void **p, size_t n, unsigned) { return hipMalloc(p, n); }
 inline hipError_t hipFree(void *p) { free(p); return hipSuccess; }
-enum { hipHostRegisterDefault = 0 };
-inline hipError_t hipHostRegister(void *, size_t, unsigned) { return hipSuccess; }
-inline hipError_t hipHostUnregister(void *) { return hipSuccess; }
+// (every emulated allocation counts as page-locked host memory: the chunked host path of the C ABI runs in the emulation)
+enum { hipMemoryTypeHost = 1 };
+struct hipPointerAttribute_t { int type; };
+inline hipError_t hipPointerGetAttributes(hipPointerAttribute_t *a, const void *) { a->type = hipMemoryTypeHost; return hipSuccess; }
 inline hipError_t hipHostFree(void *p) { free(p); return hipSuccess; }
 inline hipError_t hipMemcpy(void *d, const void *s, size_t n, hipMemcpyKind) { memcpy(d, s, n); return hipSuccess; }
 inline hipError_t hipMemcpyAsync(void *d, const void *s, size_t n, hipMemcpyKind, hipStream_t) { memcpy(d, s, n); return hipSuccess; }
@@ -155,4 +156,5 @@ inline int update_dpp(int old, int src, int ctrl, int row_mask, int bank_mask, b
 #define __builtin_amdgcn_update_dpp(old, src, ctrl, rm, bm, bc) hipemu::update_dpp((old), (src), (ctrl), (rm), (bm), (bc))
 #define __builtin_amdgcn_fence(...) ((void)0)
 #define __builtin_amdgcn_wave_barrier() hipemu::wave_barrier()
+inline void __syncthreads() { hipemu::wave_barrier(); }  // (mode 0: the barrier spans the block's threads; kernels that use it must run in that mode)
 #define hipLaunchKernelGGL(kernel, grid, block, smem, stream, ...) hipemu::launch((grid), (block), (smem), [&]() { kernel(__VA_ARGS__); })

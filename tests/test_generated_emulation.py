@@ -377,6 +377,28 @@ def test_emulated_fdsva_so(name, libs, golden):
             assert np.abs(got[t] - ref[t]).max() <= TOL * max(np.abs(ref[t]).max(), 1e-3), (k, t)
 
 
+@pytest.mark.parametrize("name,tuning", [("atlas", {"so_split": False}), ("hyq", {"so_blocked": False}), ("tree12", {"so_origin": "base"})])
+def test_emulated_fdsva_so_variants_agree_with_the_shipped_form(name, tuning, libs, golden):
+    """The forms the shipped second-order kernels replaced stay available as tuning variants and give the same tensors: the single-kernel fdsva_so of the
+    30-DoF humanoid (the C ABI runs prepare + contract kernels there; the single fdsva_so_kernel is what a caller launching it himself gets), the dense
+    (not block-diagonal) contraction, and the tree form about the base origin (fp32: equal to ~1e-4 of the tensor's largest entry only - the reason it was replaced)."""
+    g = golden(name)
+    a = libs(name)
+    b = emu_library(name, max_timesteps=8, tuning=tuning)
+    n, N = a.n, 2
+    x = np.ascontiguousarray(np.hstack([g["q"], g["qd"], g["u"]]).astype(np.float32)[:N])
+    outs = []
+    for lib in (a, b):
+        o = np.full((N, 4 * n ** 3), np.nan, np.float32)
+        lib.fdsva_so_device(x, N, o)
+        assert np.isfinite(o).all()
+        outs.append(o.reshape(N, 4, -1))
+    tol = 2e-3 if "so_origin" in tuning else 2e-5
+    for k in range(N):
+        for t in range(4):
+            assert np.abs(outs[0][k, t] - outs[1][k, t]).max() <= tol * max(np.abs(outs[0][k, t]).max(), 1e-3)
+
+
 def _random_tree_description(seed, n):
     """A random fixed-base tree of n revolute joints (ids in DFS pre-order, random axes, offsets, inertias); branches stay below 16 joints."""
     rng = np.random.default_rng(seed)

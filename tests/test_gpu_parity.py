@@ -82,8 +82,8 @@ def test_fd_grad_matches_oracle_on_seeded_inputs(name, N, torch_cuda, libs):
 
 def test_chunked_host_entry_point_gives_the_same_records_as_one_launch(torch_cuda, golden):
     """The hot path's host entry point cuts batches of >= 4096 solves into up to four chunks that travel on the handle's three streams (H2D, kernel and D2H of
-    neighbouring chunks overlap; the caller's buffers are pinned for the call: csrc/grid_capi.hip fd_grad_host).  Ragged chunk sizes, pageable NumPy buffers,
-    bit-identical to a single device-pointer launch; and the same through the single-process multi-handle driver.  (Checked once on the CPU emulation too; it
+    neighbouring chunks overlap) where the caller's buffers are page-locked (grid_host_alloc / GridLibrary.pinned_empty: csrc/grid_capi.hip fd_grad_host).
+    Ragged chunk sizes, pageable and page-locked NumPy buffers, bit-identical to a single device-pointer launch; and the same through the single-process multi-handle driver.  (Checked once on the CPU emulation too; it
     is a 10-minute test there.)"""
     from gridcodegenerator_amd.runtime import MultiGpuGrid
 
@@ -96,9 +96,14 @@ def test_chunked_host_entry_point_gives_the_same_records_as_one_launch(torch_cud
             x = np.ascontiguousarray(np.tile(np.hstack([g["q"], g["qd"], g["u"]]).astype(np.float32), (-(-N // 16), 1))[:N])
             x[:, :n] += np.linspace(0, 0.3, N, dtype=np.float32)[:, None]
             one = run_fd_grad(torch_cuda, lib, x)
-            out = lib.forward_dynamics_gradient_host(x)
+            out = lib.forward_dynamics_gradient_host(x)            # pageable buffers: the sequential form
             assert np.isfinite(out).all() and np.array_equal(out, one), N
+            xp, op = lib.pinned_empty(x.shape), lib.pinned_empty(one.shape)   # page-locked buffers: the chunked pipeline
+            xp[:] = x
+            op[:] = np.nan
+            assert lib.forward_dynamics_gradient_host(xp, out=op) is op and np.array_equal(op, one), N
             assert np.array_equal(multi.forward_dynamics_gradient_host(x), one), N
+            del xp, op
     finally:
         multi.close()
         lib.close()
