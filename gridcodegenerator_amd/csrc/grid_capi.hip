@@ -39,6 +39,7 @@ struct grid_handle {
     int max_timesteps;
     int blocks;   // 0 = derive from the batch
     int threads;  // 0 = the kernel's suggested block size
+    int host_chunks;  // 0 = automatic: chunks of the pipelined host entry point (page-locked buffers)
     hipStream_t *streams;
     grid_typed<float> f32;
     grid_typed<double> f64;  // allocated by the first *_f64 call
@@ -422,7 +423,8 @@ static int fd_grad_host(grid_handle *h, const T *h_q_qd_u, int N, T gravity, T *
     grid::gridData<T> *d = typed<T>(h).hd_data;
     const int min_chunk = 2048;  // (below that a chunk's kernel is all launch latency)
     int chunks = N / min_chunk;
-    if (chunks > 4) chunks = 4;
+    if (chunks > 3) chunks = 3;  // (one chunk per stream; measured at 16 384 solves, page-locked buffers: 1 chunk 178 us, 2: 176, 3: 172.5, 4: 206, 8: 244 - tools/bench_host_pipeline.py)
+    if (h->host_chunks > 0) chunks = h->host_chunks < N ? h->host_chunks : N;
     if (chunks < 2 || !is_pinned_host(h_q_qd_u) || !is_pinned_host(h_df_du)) {
         hipStream_t s = h->streams[0];
         GRID_H2D(d->d_q_qd_u, h_q_qd_u, 3 * n * N);
@@ -617,7 +619,7 @@ int grid_init(int device, int max_timesteps, grid_handle **out) {
     if (!h) return fail_msg(hipErrorOutOfMemory, "grid_init: out of host memory");
     h->device = device;
     h->max_timesteps = max_timesteps;
-    h->blocks = h->threads = 0;
+    h->blocks = h->threads = h->host_chunks = 0;
     h->streams = nullptr;
     int rc = 0;
     try {
@@ -652,6 +654,11 @@ int grid_close(grid_handle *h) {
 
 int grid_device(const grid_handle *h) { return h ? h->device : -1; }
 
+int grid_set_host_chunks(grid_handle *h, int chunks) {
+    if (!h || chunks < 0 || chunks > 64) return fail_msg(hipErrorInvalidValue, "grid_set_host_chunks: chunks must be 0 (automatic) .. 64");
+    h->host_chunks = chunks;
+    return 0;
+}
 int grid_host_alloc(size_t bytes, void **out) {
     if (!out) return fail_msg(hipErrorInvalidValue, "grid_host_alloc: null result pointer");
     *out = nullptr;

@@ -52,6 +52,7 @@ int grid_device(const grid_handle *h);
 /* Page-locked host buffers (hipHostMalloc / hipHostFree).  Replaces the pinned h_* members of gridData that the reference's callers fill and read
  * (reference GRiDCodeGenerator.py:160-213 allocates them with malloc; ours with hipHostMalloc).  grid_forward_dynamics_gradient_host overlaps its
  * copies with the kernel when BOTH of its buffers come from here (or are otherwise page-locked); pageable buffers take the sequential form. */
+int grid_set_host_chunks(grid_handle *h, int chunks); /* chunks of the pipelined host entry point; 0 = automatic (tuning aid, like grid_set_launch_dims) */
 int grid_host_alloc(size_t bytes, void **out);
 int grid_host_free(void *p);
 /* solves per call the second-order entry points accept on this handle: min(max_timesteps, 1 GiB / record) - the generated init_gridData<T>()

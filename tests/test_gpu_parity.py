@@ -92,7 +92,7 @@ def test_chunked_host_entry_point_gives_the_same_records_as_one_launch(torch_cud
     multi = MultiGpuGrid(lib.path, devices=[0, 0], max_timesteps=16384)
     n = lib.n
     try:
-        for N in (4100, 6151, 16384, 4095):  # two chunks of 2050; three chunks of 2051 / 2051 / 2049; four of 4096; one launch
+        for N in (4100, 6151, 16384, 4095):  # two chunks of 2050; three chunks of 2051 / 2051 / 2049; three of 5462 / 5462 / 5460; one launch
             x = np.ascontiguousarray(np.tile(np.hstack([g["q"], g["qd"], g["u"]]).astype(np.float32), (-(-N // 16), 1))[:N])
             x[:, :n] += np.linspace(0, 0.3, N, dtype=np.float32)[:, None]
             one = run_fd_grad(torch_cuda, lib, x)
