@@ -7,6 +7,7 @@ import collections, csv, glob, json, os, shutil, sys
 base, tag = sys.argv[1].rstrip("/") + "/", sys.argv[2]
 cfgs = sys.argv[3:] or ["iiwa14", "65536", "atlas", "1024"]
 P = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles")
+KERNELS = ("idsva_so_kernel", "fdsva_so_kernel", "fdsva_so_prepare_kernel", "fdsva_so_contract_kernel")  # (the humanoid's fdsva_so runs as prepare + contract)
 N_OF = {"iiwa14": 7, "arm6": 6, "hyq": 12, "tree12": 12, "atlas": 30, "chain8": 8, "chain12": 12, "mixed5": 5}
 
 
@@ -35,14 +36,14 @@ for robot, N in zip(cfgs[0::2], (int(x) for x in cfgs[1::2])):
     alg = 4 * (3 * n + 4 * n ** 3) * N
     dur = {}
     for r in csv.DictReader(open(fs[0])):
-        for k in ("idsva_so_kernel", "fdsva_so_kernel"):
-            if k in r["Name"]:
+        for k in KERNELS:
+            if k + "<" in r["Name"]:
                 dur[k] = float(r["AverageNs"])
     with open(os.path.join(P, "%s_so_%s_pmc.txt" % (tag, robot)), "w") as f:
         f.write("rocprofv3 --pmc <counters> --kernel-trace -- python3 tools/bench_idsva_so.py %s %d   (tools/collect_so_profiles.sh; per launch of %d solves; separate passes)\n" % (robot, N, N))
         f.write("algorithmic HBM bytes per launch: 4*(3n + 4n^3)*N = %d\n" % alg)
-        for k in ("idsva_so_kernel", "fdsva_so_kernel"):
-            out = counters(robot, k)
+        for k in KERNELS:
+            out = counters(robot, k + "<")
             if not out:
                 continue
             w = out.get("SQ_WAVE_CYCLES", 0.0)
