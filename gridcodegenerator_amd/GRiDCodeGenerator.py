@@ -48,6 +48,7 @@ TUNING_DEFAULTS = {
                                 # (auto = only where the record does not fit LDS, algorithms/_idsva_so.py: gen_idsva_so_direct)
     "lane_interleave": True,    # 8-lane groups: the two solves of a 16-lane DPP row interleave (solve = lane parity, joint = lane / 2), so that the row's end IS
                                 # the solve's end for the lane-group scans: no masked multiply with the neighbouring solve's values (0 * NaN), no masks at all
+    "scan_form": "add",         # add | fmac: instruction of an unmasked scan step (interleaved 8-lane groups): v_add_f32_dpp x, x, x or v_fmac_f32_dpp x, x, 1.0
     "dpp_asm": True,            # lane-group scans as single v_fmac_f32_dpp instructions (inline asm) instead of builtin DPP move + FMA
     "tip_chain": "select",      # select | lds: how the tip-frame chain hands (R, p) to the owning lane
     "nt_store": True,           # non-temporal output stores

@@ -62,6 +62,18 @@ def gen_inverse_dynamics_inner(self, use_thread_group=False, use_qdd_input=False
     self.gen_add_code_line("void inverse_dynamics_inner(T (&c)[" + str(n) + "], const T *s_qd, " + ("const T *s_qdd, " if use_qdd_input else "") +
                            "const T *s_X, const T gravity) {", True)
 
+    dbg = bool(getattr(self, "DEBUG_MODE", False))
+    if dbg:
+        # the reference's DEBUG_MODE dumps (reference algorithms/_inverse_dynamics.py:73-83,137-144,238-252,298-305): same names as its NumPy oracle prints
+        # (_test.py:33-37,51-55), from the thread that owns joint 0 of the first solve of the launch; X(q) is kept in compact form here: E | B instead of 6 x 6
+        self.gen_add_code_line("const bool dbg = (threadIdx.x + threadIdx.y*blockDim.x == 0) && (blockIdx.x + blockIdx.y == 0);")
+        self.gen_add_code_line("if (dbg) {", True)
+        self.gen_add_code_line("printf(\"qd\\n\"); printMat<T,1,%d>(s_qd,1);" % n)
+        if use_qdd_input:
+            self.gen_add_code_line("printf(\"qdd\\n\"); printMat<T,1,%d>(s_qdd,1);" % n)
+        self.gen_add_code_line("for (int i = 0; i < %d; i++){printf(\"X[%%d] (compact: E rows, then B rows)\\n\",i); printMat<T,3,6>(&s_X[GRID_X_STRIDE*i],3);}" % n)
+        self.gen_add_end_control_flow()
+
     def pre(i):
         s, p = m.S_index[i], m.parent[i]
         self.gen_add_code_line("const T qd_%d = s_qd[%d];" % (i, i))
@@ -77,12 +89,16 @@ def gen_inverse_dynamics_inner(self, use_thread_group=False, use_qdd_input=False
         if use_qdd_input:
             self.gen_add_code_line("a_%d[%d] += s_qdd[%d];" % (i, s, i))
         self.gen_add_code_line("T Iv[6]; grid_imul_%d(Iv, v_%d); grid_imul_%d(f_%d, a_%d); grid_fxv_peq(f_%d, v_%d, Iv); grid_pin6(f_%d);" % (i, i, i, i, i, i, i, i))
+        if dbg:
+            self.gen_add_code_line("if (dbg) { printf(\"s_v[%d]\\n\"); printMat<T,1,6>(v_%d,1); printf(\"s_a[%d]\\n\"); printMat<T,1,6>(a_%d,1); printf(\"s_f[%d] (forward pass)\\n\"); printMat<T,1,6>(f_%d,1); }" % (i, i, i, i, i, i))
         self.gen_add_end_control_flow()
 
     def post(i):
         s, p = m.S_index[i], m.parent[i]
         damp = m.damping[i]
         self.gen_add_code_line("c[%d] = f_%d[%d]%s; grid_pin(c[%d]);" % (i, i, s, (" + static_cast<T>(" + repr(float(damp)) + ")*qd_" + str(i)) if damp != 0.0 else "", i))
+        if dbg:
+            self.gen_add_code_line("if (dbg) { printf(\"s_f[%d] (after the backward pass)\\n\"); printMat<T,1,6>(f_%d,1); printf(\"c[%d] = %%.4f\\n\", static_cast<double>(c[%d])); }" % (i, i, i, i))
         if p != -1:
             self.gen_add_code_line("{ T X[18]; grid_load_X(X, &s_X[GRID_X_STRIDE*%d]); grid_xtmul_peq(f_%d, X, f_%d); grid_pin6(f_%d); }" % (i, p, i, p))
 

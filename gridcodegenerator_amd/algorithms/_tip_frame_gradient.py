@@ -202,7 +202,10 @@ def gen_tip_frame_library(self):
                     for lo in range(0, N, 6):
                         cnt = min(6, N - lo)
                         outs = ", ".join('"+v"(x[%d])' % (lo + r) for r in range(cnt))
-                        if unmasked:  # x += (the value 2k lanes away, 0 beyond the row): one v_add_f32_dpp
+                        if unmasked and self.tuning["scan_form"] == "fmac":  # x += 1 * (the value 2k lanes away, 0 beyond the row)
+                            body = "s_nop 1" + "".join("\\n\\tv_fmac_f32_dpp %%%d, %%%d, %%%d %s:%d row_mask:0xf bank_mask:0xf bound_ctrl:1" % (r, r, cnt, ctrl, k * stride) for r in range(cnt))
+                            self.gen_add_code_line('{ const float one = 1.0f; asm("%s" : %s : "v"(one)); }' % (body, outs))
+                        elif unmasked:  # x += (the value 2k lanes away, 0 beyond the row): one v_add_f32_dpp
                             body = "s_nop 1" + "".join("\\n\\tv_add_f32_dpp %%%d, %%%d, %%%d %s:%d row_mask:0xf bank_mask:0xf bound_ctrl:1" % (r, r, r, ctrl, k * stride) for r in range(cnt))
                             self.gen_add_code_line('asm("%s" : %s);' % (body, outs))
                         else:

@@ -34,14 +34,14 @@ def library_path(robot_name, build_dir=None):
     return os.path.join(build_dir or BUILD_DIR, robot_name, "libgrid_%s.so" % robot_name)
 
 
-def generate_header(robot, out_dir, namespace="grid", cols_per_lane=None, tuning=None):
+def generate_header(robot, out_dir, namespace="grid", cols_per_lane=None, tuning=None, debug_mode=False):
     """Runs GRiDCodeGenerator(robot).gen_all_code() with out_dir as the working directory (the generator writes
     <namespace>.cuh into the cwd, like the reference does)."""
     os.makedirs(out_dir, exist_ok=True)
     cwd = os.getcwd()
     os.chdir(out_dir)
     try:
-        GRiDCodeGenerator(robot, FILE_NAMESPACE=namespace, COLS_PER_LANE=cols_per_lane, tuning=tuning).gen_all_code()
+        GRiDCodeGenerator(robot, DEBUG_MODE=debug_mode, FILE_NAMESPACE=namespace, COLS_PER_LANE=cols_per_lane, tuning=tuning).gen_all_code()
     finally:
         os.chdir(cwd)
     return os.path.join(out_dir, namespace + ".cuh")

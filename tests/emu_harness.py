@@ -12,14 +12,14 @@ EMU_INC = os.path.join(HERE, "emu")
 _CACHE = {}
 
 
-def emu_library(robot, max_timesteps=64, cols_per_lane=None, tuning=None):
+def emu_library(robot, max_timesteps=64, cols_per_lane=None, tuning=None, debug_mode=False):
     """tuning: generation-time knobs (GRiDCodeGenerator(..., tuning=...)) for this build only."""
     if isinstance(robot, str):
         robot = RobotModel.from_fixture(robot)
-    key = robot.name + ("" if cols_per_lane is None else "_c%d" % cols_per_lane) + "".join("_%s%s" % (k, v) for k, v in sorted((tuning or {}).items()))
+    key = robot.name + ("" if cols_per_lane is None else "_c%d" % cols_per_lane) + ("_debug" if debug_mode else "") + "".join("_%s%s" % (k, v) for k, v in sorted((tuning or {}).items()))
     if key not in _CACHE:
         out_dir = os.path.join(tempfile.gettempdir(), "grid_emu_build", key)
-        generate_header(robot, out_dir, cols_per_lane=cols_per_lane, tuning=tuning)
+        generate_header(robot, out_dir, cols_per_lane=cols_per_lane, tuning=tuning, debug_mode=debug_mode)
         so = os.path.join(out_dir, "libgrid_emu_%s.so" % key)
         cmd = ["g++", "-std=c++20", "-O0", "-g0", "-fno-gnu-unique",  # (no process-wide "unique" symbols: inline variables and function-local statics stay private to each robot library)
                "-x", "c++", "-shared", "-fPIC", "-pthread", "-I" + EMU_INC, "-I" + out_dir, "-I" + INCLUDE_DIR,

@@ -488,3 +488,31 @@ def test_emulated_run_longer_than_a_dpp_row_is_split_into_branches():
     ref, _ = Oracle(robot).fd_grad_batch(x.astype(np.float64))
     lib.set_launch_dims(0, 64)
     assert per_solve_err(lib.forward_dynamics_gradient_host(x), ref) <= TOL
+
+
+def test_emulated_debug_mode_dumps_the_rnea_intermediates_the_reference_prints(golden, capfd):
+    """the reference's comparison mechanism is DEBUG_MODE - the emitted kernels print the same-named intermediates as its NumPy oracle
+    (reference algorithms/_inverse_dynamics.py:73-83,137-144,238-252).  The generated RNEA prints s_v / s_a / s_f per joint (forward pass and after the
+    backward pass) and c for the first solve of the launch; the numbers are the oracle's v, a, f, c of the goldens."""
+    import re
+
+    g = golden("iiwa14")
+    lib = emu_library("iiwa14", max_timesteps=4, debug_mode=True, tuning={"so_lanes": "off"})
+    n = lib.n
+    x = np.ascontiguousarray(np.hstack([g["q"], g["qd"], g["u"]]).astype(np.float32)[:1])
+    qdd = np.ascontiguousarray(g["qdd"].astype(np.float32)[:1])
+    c = np.zeros((1, n), np.float32)
+    capfd.readouterr()
+    lib.inverse_dynamics_device(x, qdd, 1, c)
+    import ctypes
+    ctypes.CDLL(None).fflush(None)  # (the C library buffers printf output when stdout is a pipe)
+    out = capfd.readouterr().out
+    assert np.abs(c[0] - g["c2"][0]).max() <= 1e-4 * np.abs(g["c2"][0]).max()
+    vec = lambda tag: [float(t) for t in re.search(re.escape(tag) + r"\n([-0-9. e+]+)\n", out).group(1).split()]
+    for j in range(n):
+        for nm, tag in (("v2", "s_v[%d]" % j), ("a2", "s_a[%d]" % j), ("f2", "s_f[%d] (after the backward pass)" % j)):
+            if nm in g:
+                ref = g[nm][0][:, j] if g[nm][0].shape[0] == 6 else g[nm][0][j]
+                assert np.abs(np.array(vec(tag)) - ref).max() <= 2e-3 * max(1.0, np.abs(ref).max()), (tag, vec(tag), ref)
+        assert ("c[%d] = " % j) in out and ("s_f[%d] (forward pass)" % j) in out
+    assert "qdd\n" in out and "X[0] (compact" in out
