@@ -125,7 +125,7 @@ class GRiDCodeGenerator:
         gen_forward_dynamics_inner_function_call, gen_forward_dynamics_inner, gen_forward_dynamics_device, gen_forward_dynamics_kernel, \
         gen_forward_dynamics_host, gen_forward_dynamics, \
         gen_aba_inner_temp_mem_size, gen_aba_inner_function_call, gen_aba_inner, gen_aba_device, gen_aba_kernel, gen_aba_host, gen_aba, \
-        gen_idsva_so_available, gen_idsva_so_mode, gen_idsva_so_direct, gen_idsva_so_compact, gen_idsva_so_compact_layout, gen_idsva_so_rec, gen_idsva_so_tree_tables, gen_idsva_so_items, gen_idsva_so_items_table, gen_idsva_so_lds_layout, gen_idsva_so_inner_temp_mem_size, gen_idsva_so_inner_function_call, gen_idsva_so_inner, gen_idsva_so_device, gen_idsva_so_kernel, gen_idsva_so_host, gen_idsva_so, \
+        gen_idsva_so_available, gen_idsva_so_mode, gen_idsva_so_direct, gen_idsva_so_compact, gen_idsva_so_blocks, gen_idsva_so_packed, gen_idsva_so_blocks_layout, gen_idsva_so_chain_compact_layout, gen_idsva_so_compact_layout, gen_idsva_so_rec, gen_idsva_so_tree_tables, gen_idsva_so_items, gen_idsva_so_items_table, gen_idsva_so_lds_layout, gen_idsva_so_inner_temp_mem_size, gen_idsva_so_inner_function_call, gen_idsva_so_inner, gen_idsva_so_device, gen_idsva_so_kernel, gen_idsva_so_host, gen_idsva_so, \
         gen_fdsva_so_inner_temp_mem_size, gen_fdsva_so_stage_size, gen_fdsva_so_fused_layout, gen_fdsva_so_components, gen_fdsva_so_split, gen_fdsva_so_split_kernels, gen_fdsva_so_lds_per_solve, gen_fdsva_so_fused_device, gen_fdsva_so_inner, gen_fdsva_so_device, gen_fdsva_so_kernel, gen_fdsva_so_host, gen_fdsva_so, \
         gen_inverse_dynamics_gradient_inner_temp_mem_size, gen_inverse_dynamics_gradient_kernel_max_temp_mem_size, \
         gen_inverse_dynamics_gradient_inner_function_call, gen_inverse_dynamics_gradient_inner, gen_dc_du_to_lds, gen_gradient_slots, gen_gradient_outputs_decl, \
@@ -324,7 +324,7 @@ class GRiDCodeGenerator:
             sl_, scr_, stg_, thr_ = self.gen_idsva_so_lds_layout()
             if scr_ > lds["MINV"] - lds["X"]:
                 raise ValueError("idsva_so scratch (%d) does not fit between X(q) and M^-1 of the general slice (fdsva_so_device runs it there)" % scr_)
-            self.gen_add_code_line("#define GRID_SO_COMPACT %d // 1: the kernels stage the idsva_so record of a solve in compact form (every value once) and expand it through grid_so_expand" % (1 if self.gen_idsva_so_compact() else 0))
+            self.gen_add_code_line("#define GRID_SO_COMPACT %d // 1: the kernels stage the idsva_so record of a solve in compact form (every value once) and expand it through grid_so_expand" % (1 if self.gen_idsva_so_packed() else 0))
             self.gen_add_code_line("#define GRID_SO_SPLIT %d // 1: the host wrappers (and the C ABI) run fdsva_so as two kernels: fdsva_so_prepare_kernel + fdsva_so_contract_kernel" % (1 if self.gen_fdsva_so_split() is not None else 0))
             self.gen_add_code_lines(["#define GRID_SO_DIRECT %d // 1: the 4 n^3 record of one solve does not fit LDS - idsva_so writes it entry by entry to global memory, fdsva_so_kernel takes a d_idsva_so workspace" % (1 if self.gen_idsva_so_direct() else 0),
                                      "// init_gridData sizes the second-order buffers (d_idsva_so, d_df2 and their pinned host twins: 4 n^3 values per solve) for at most this many solves",

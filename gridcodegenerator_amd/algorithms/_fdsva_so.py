@@ -101,15 +101,14 @@ for (int k = @K0@; k < @N@; k += @KSTEP@) {
 # (uniform trip count = the largest component, shorter components masked): 18^4 + 2 6^4 instead of 30^4 multiply-adds per tensor on the 30-DoF
 # humanoid (7.5x fewer), 4 3^4 instead of 12^4 on the quadruped; the entries that couple different components are exact zeros (zero fill of the record).
 _BLOCKED = """
-const T *tqq = s_idsva_so, *tvv = s_idsva_so + @N3@, *tvq = s_idsva_so + 2*@N3@, *dM = s_idsva_so + 3*@N3@;
-const int j = (lane < @N@) ? lane : 0;
-const bool own = active && (lane < @N@);
+@SPLIT@
 const int c0 = grid_so_component[2*j], cs = grid_so_component[2*j + 1]; // first joint and size of the base-rooted component of joint j
+@TENSORS@
 if (active) { for (int e = lane; e < 4*@N3@; e += GRID_LANES_PER_SOLVE) { df2[e] = static_cast<T>(0); } } // (entries that couple different components; the same wave overwrites the others below)
 grid_wave_sync(); // (the fill and the entries are ordered by the wave's program order; lane-per-thread execution models need the hand-off point)
-const T *fq_j = &s_df_du[j*@N@ + c0], *fv_j = &s_df_du[(@N@ + j)*@N@ + c0], *mi_j = &s_Minv[j*@LD@ + c0]; // column j of df/dq and of df/dqd, row j of M^-1 (rows of the component)
+@COLJ@
 #pragma unroll 1
-for (int kk = 0; kk < @MAXC@; kk++) {
+for (int kk = @K0@; kk < @MAXC@; kk += @KSTEP@) {
     const bool vk = kk < cs; const int k = c0 + (vk ? kk : 0);
     const T *fq_k = &s_df_du[k*@N@ + c0];
     T oq[@MAXC@], oc[@MAXC@], ov[@MAXC@], ot[@MAXC@]; // out_x[c0 + i][k][j]
@@ -118,14 +117,12 @@ for (int kk = 0; kk < @MAXC@; kk++) {
     #pragma unroll 1
     for (int LL = 0; LL < @MAXC@; LL++) {
         const bool vL = LL < cs; const int L = c0 + (vL ? LL : 0);
-        const T *dMk = &dM[(L*@N@ + k)*@N@ + c0], *dMj = &dM[(L*@N@ + j)*@N@ + c0];
-        T aq = tqq[(L*@N@ + k)*@N@ + j], ac = tvq[(L*@N@ + k)*@N@ + j], at = static_cast<T>(0);
-        const T av = tvv[(L*@N@ + k)*@N@ + j];
+        @ROWS@
         #pragma unroll @PUNROLL@
         for (int pp = 0; pp < @MAXC@; pp++) {
             const bool vp = pp < cs; const int p = vp ? pp : 0;
             const T mk = vp ? dMk[p] : static_cast<T>(0), mj = vp ? dMj[p] : static_cast<T>(0);
-            aq += mj*fq_k[p] + mk*fq_j[p]; ac += mk*fv_j[p]; at += mk*mi_j[p];
+            aq += mj*fq_k[p] + mk*fq_j[@PJ@]; ac += mk*fv_j[@PJ@]; at += mk*mi_j[@PJ@];
         }
         #pragma unroll
         for (int i = 0; i < @MAXC@; i++) { const T mi = (vL && i < cs) ? s_Minv[L*@LD@ + c0 + ((i < cs) ? i : 0)] : static_cast<T>(0); oq[i] += mi*aq; oc[i] += mi*ac; ov[i] += mi*av; ot[i] += mi*at; }
@@ -167,7 +164,7 @@ def gen_fdsva_so_stage_size(self):
     """Per-solve staging behind the block's slices: df/du (2 n^2, padded) then the idsva_so tensors (4 n^3; in the direct form of large robots they
     stay in a global workspace, gen_idsva_so_direct)."""
     n = self.model.n
-    return (2 * n * n + 3) // 4 * 4 + (0 if self.gen_idsva_so_direct() else (self.gen_idsva_so_compact_layout()["SIZE"] if self.gen_idsva_so_compact() else 4 * n * n * n))
+    return (2 * n * n + 3) // 4 * 4 + (0 if self.gen_idsva_so_direct() else (self.gen_idsva_so_compact_layout()["SIZE"] if self.gen_idsva_so_packed() else 4 * n * n * n))
 
 
 def gen_fdsva_so_inner(self, use_thread_group=False):
@@ -177,7 +174,7 @@ def gen_fdsva_so_inner(self, use_thread_group=False):
     self.gen_add_func_doc("Second Order of Forward Dynamics with Spatial Vector Algebra: the contraction of the idsva_so tensors with M^-1 and df/du",
                           ["lane j produces the entries (., k, j) of the four output tensors and stores each exactly once; all lanes of the lane group must call it"],
                           ["df2 is the output record of this solve: 4*NUM_JOINTS^3 values [d2a_dqdq | d2a_dvdv | d2a_dvdq | d2a_dtdq] (global or LDS memory)",
-                           "s_idsva_so are the second derivative tensors of inverse dynamics at qdd = FD(q, qd, u), in LDS (large robots: global workspace)" + ("; COMPACT staging record (idsva_so_inner_compact)" if self.gen_idsva_so_compact() else ""),
+                           "s_idsva_so are the second derivative tensors of inverse dynamics at qdd = FD(q, qd, u), in LDS (large robots: global workspace)" + ("; COMPACT staging record (idsva_so_inner_compact)" if self.gen_idsva_so_packed() else ""),
                            "s_Minv is the dense symmetric inverse mass matrix in LDS (leading dimension GRID_MINV_LD)",
                            "s_df_du is the gradient of the forward dynamics in LDS ([col*n + row], col in [0, 2n))",
                            "lane is the caller's lane index inside the solve's lane group", "active is false for lane groups without a solve"], None)
@@ -219,12 +216,30 @@ for (int k = @K0@; k < @N@; k += @KSTEP@) {
 }
 """)
     G = self.lanes_per_solve
-    if (n <= 12 or compact) and G // 2 >= n and blocked is None:  # lane groups at least twice as wide as the robot has joints (the `wide` instances): the two halves of the group take alternate k
-        lines = lines.replace("@SPLIT@", "const int jl = lane %% %d, kh = lane / %d; // joint and k parity of this lane\nconst int j = (jl < @N@) ? jl : 0;\nconst bool own = active && (jl < @N@);" % (G // 2, G // 2)).replace("@K0@", "kh").replace("@KSTEP@", "2")
+    if (n <= 12 or compact) and G // 2 >= n:  # lane groups at least twice as wide as the robot has joints (the `wide` instances): the two halves of the group take alternate k
+        lines = lines.replace("@SPLIT@", "const int jh = lane %% %d, kh = lane / %d; // joint and k parity of this lane\nconst int j = (jh < @N@) ? jh : 0;\nconst bool own = active && (jh < @N@);" % (G // 2, G // 2)).replace("@K0@", "kh").replace("@KSTEP@", "2")
     else:
         lines = lines.replace("@SPLIT@", "const int j = (lane < @N@) ? lane : 0;\nconst bool own = active && (lane < @N@);").replace("@K0@", "0").replace("@KSTEP@", "1")
     if blocked is not None:
-        lines = lines.replace("@MAXC@", str(blocked[1])).replace("@PUNROLL@", str(min(6, blocked[1])))
+        if self.gen_idsva_so_blocks():  # the tensors are staged as the dense blocks of the components: [tensor][L - c0][k - c0][j - c0] at the block's base
+            tensors = ("const int cs3 = cs*cs*cs; const T *tqq = s_idsva_so + grid_so_blocks[3*j + 2], *tvv = tqq + cs3, *tvq = tqq + 2*cs3, *dM = tqq + 3*cs3; const int jl = j - c0; // (block staging)")
+            rows = ("const int LLc = vL ? LL : 0, kkc = vk ? kk : 0; const T *dMk = &dM[(LLc*cs + kkc)*cs], *dMj = &dM[(LLc*cs + jl)*cs];\n"
+                    "        T aq = tqq[(LLc*cs + kkc)*cs + jl], ac = tvq[(LLc*cs + kkc)*cs + jl], at = static_cast<T>(0);\n"
+                    "        const T av = tvv[(LLc*cs + kkc)*cs + jl];")
+        else:
+            tensors = "const T *tqq = s_idsva_so, *tvv = s_idsva_so + @N3@, *tvq = s_idsva_so + 2*@N3@, *dM = s_idsva_so + 3*@N3@;"
+            rows = ("const T *dMk = &dM[(L*@N@ + k)*@N@ + c0], *dMj = &dM[(L*@N@ + j)*@N@ + c0];\n"
+                    "        T aq = tqq[(L*@N@ + k)*@N@ + j], ac = tvq[(L*@N@ + k)*@N@ + j], at = static_cast<T>(0);\n"
+                    "        const T av = tvv[(L*@N@ + k)*@N@ + j];")
+        if blocked[1] <= 12:  # small components: column j of df/dq, df/dqd and row j of M^-1 wait in registers (three LDS reads fewer per inner step)
+            colj = ("T fq_j[@MAXC@], fv_j[@MAXC@], mi_j[@MAXC@]; // column j of df/dq and of df/dqd, row j of M^-1 (rows of the component)\n"
+                    "#pragma unroll\n"
+                    "for (int p = 0; p < @MAXC@; p++) { const int pc = (p < cs) ? p : 0; fq_j[p] = s_df_du[j*@N@ + c0 + pc]; fv_j[p] = s_df_du[(@N@ + j)*@N@ + c0 + pc]; mi_j[p] = s_Minv[j*@LD@ + c0 + pc]; }")
+        else:
+            colj = "const T *fq_j = &s_df_du[j*@N@ + c0], *fv_j = &s_df_du[(@N@ + j)*@N@ + c0], *mi_j = &s_Minv[j*@LD@ + c0]; // column j of df/dq and of df/dqd, row j of M^-1 (rows of the component)"
+        lines = lines.replace("@COLJ@", colj).replace("@PJ@", "pp" if blocked[1] <= 12 else "p")
+        lines = lines.replace("@TENSORS@", tensors).replace("@ROWS@", rows)
+        lines = lines.replace("@PUNROLL@", str(blocked[1] if blocked[1] <= 12 else 6)).replace("@MAXC@", str(blocked[1]))
     if compact:
         L_ = self.gen_idsva_so_compact_layout()
         for k_ in ("Q2", "QD2", "VQ", "MQ", "TRI"):
@@ -315,7 +330,7 @@ def gen_fdsva_so_device(self, use_thread_group=False, prepare=False):
         self.gen_add_code_line("forward_dynamics_gradient_device<T>(s_df_du, s_q, s_qd, s_u, s_work, d_robotModel, gravity, lane);")
         self.gen_add_code_line("forward_dynamics_device<T>(s_qdd, s_q, s_qd, s_u, s_work, d_robotModel, gravity, lane);")
         self.gen_add_code_line("direct_minv_device<T>(s_Minv, s_q, s_work, d_robotModel, lane);")
-    self.gen_add_code_line("idsva_so_device%s<T>(s_idsva_so, s_q, s_qd, s_qdd, &s_work[GRID_OFF_X], d_robotModel, gravity, lane, %s);" % ("_compact" if self.gen_idsva_so_compact() else "", "active" if self.gen_idsva_so_direct() else "true"))
+    self.gen_add_code_line("idsva_so_device%s<T>(s_idsva_so, s_q, s_qd, s_qdd, &s_work[GRID_OFF_X], d_robotModel, gravity, lane, %s);" % ("_compact" if self.gen_idsva_so_packed() else "", "active" if self.gen_idsva_so_direct() else "true"))
     self.gen_add_sync(use_thread_group)
     self.gen_add_code_line("fdsva_so_inner<T>(df2, s_idsva_so, s_Minv, s_df_du, lane, active);")
     self.gen_add_end_function()

@@ -77,7 +77,7 @@ def gen_idsva_so_lds_layout(self):
     sl = pad4(3 * n) + scratch
     if (sl // 4) % 2 == 0:
         sl += 4
-    stage = 0 if self.gen_idsva_so_direct() else (self.gen_idsva_so_compact_layout()["SIZE"] if self.gen_idsva_so_compact() else 4 * n * n * n)
+    stage = 0 if self.gen_idsva_so_direct() else (self.gen_idsva_so_compact_layout()["SIZE"] if self.gen_idsva_so_packed() else 4 * n * n * n)
     # block size: full waves unless fewer lane groups per block let at least a quarter more solves be resident on a CU (quadruped, 32-lane groups, 16 384
     # solves: one solve per block 231 us, two 274; 6-DoF arm, 16-lane groups, 65 536 solves: four per block 135 us, three - 8 % more resident - 180)
     per = (sl + stage) * 4
@@ -122,8 +122,7 @@ def gen_idsva_so_inner_function_call(self, use_thread_group=False, use_qdd_input
 
 def gen_idsva_so_inner(self, use_thread_group=False, use_qdd_input=False, compact=False):
     if self.gen_idsva_so_mode() == "tree":
-        assert not compact
-        return gen_idsva_so_inner_tree(self, use_thread_group)
+        return gen_idsva_so_inner_tree(self, use_thread_group, blocks=compact)
     return gen_idsva_so_inner_chain(self, use_thread_group, compact)
 
 
@@ -180,7 +179,58 @@ def gen_idsva_so_compact(self):
     return ok and want != "dense"
 
 
+def gen_idsva_so_blocks(self):
+    """True where the tree form stages a solve's record as the dense BLOCKS of the robot's base-rooted components (tuning so_stage): a fixed base decouples the
+    components, so every entry with indices in different components is a structural zero - the quadruped's record shrinks from 6 912 to 432 values (4 x 4 x 3^3),
+    the 12-DoF tree's from 6 912 to 4 032; the dense record is gathered through grid_so_expand on the way out, like the compact form of serial chains."""
+    want = self.tuning["so_stage"]
+    if want not in ("auto", "compact", "dense"):
+        raise ValueError("tuning['so_stage'] must be auto, compact or dense")
+    return (self.gen_idsva_so_mode() == "tree" and not self.gen_idsva_so_direct() and len(self.model.roots) > 1 and want != "dense" and self.tuning["so_blocked"]
+            and self.tuning["so_mapping"] == "balanced" and self.tuning["so_loops"] == "dots")  # (so_blocked: fdsva_so's contraction reads the blocks)
+
+
+def gen_idsva_so_packed(self):
+    """The kernels stage a packed record (compact: serial chains; blocks: trees with several components) and expand it through grid_so_expand."""
+    return self.gen_idsva_so_compact() or self.gen_idsva_so_blocks()
+
+
+def gen_idsva_so_blocks_layout(self):
+    """Block staging: component kappa (joints c0 .. c0 + cs - 1) owns 4 cs^3 values at BASE[kappa]: [tensor][i - c0][a - c0][b - c0]; then the ZERO slot.
+    Returns SIZE, the per-joint table [c0, cs, base] (flat, one triple per lane of the lane group) and the expansion table."""
+    m = self.model
+    n = m.n
+    comps, base = {}, 0
+    for r in m.roots:
+        cs = len(m.subtree[r])
+        for j_ in m.subtree[r]:
+            comps[j_] = (r, cs, base)
+        base += 4 * cs ** 3
+    L = {"ZERO": base, "SIZE": (base + 1 + 3) // 4 * 4}
+    flat = []
+    for j_ in range(self.lanes_per_solve):
+        flat += list(comps.get(j_, (0, 0, 0)))
+    L["JOINTS"] = flat
+    table = []
+    for ten in range(4):
+        for i in range(n):
+            for a in range(n):
+                for b in range(n):
+                    (c0, cs, bs) = comps[i]
+                    same = comps[a][0] == c0 and comps[b][0] == c0
+                    table.append(bs + ten * cs ** 3 + ((i - c0) * cs + (a - c0)) * cs + (b - c0) if same else L["ZERO"])
+    assert max(table) < 65536
+    L["TABLE"] = table
+    return L
+
+
 def gen_idsva_so_compact_layout(self):
+    if self.gen_idsva_so_blocks():
+        return self.gen_idsva_so_blocks_layout()
+    return self.gen_idsva_so_chain_compact_layout()
+
+
+def gen_idsva_so_chain_compact_layout(self):
     """Offsets of the compact staging record and the expansion table (slot of every element of the dense record [d2tau_dq2 | d2tau_dqd2 | d2tau_dvdq | dM_dq]).
     q2c / qd2c: [i][tri(b) + a], a <= b, tri(b) = b (b + 1) / 2;  vq: dense [i][a][b];  mqc: [tri(k) + i][j], i <= k (structurally zero for j <= i:
     those slots are never written and never read - the table sends the elements to the ZERO slot);  then ZERO and a DUMMY slot for predicated-off stores."""
@@ -304,11 +354,17 @@ class _SoStores:
     """Store statements of the second-order main loops for one staging form.  dense: the record itself, [t][i][a][b] at t n^3 + (i n + a) n + b, symmetric
     entries written twice; compact (gen_idsva_so_compact_layout): every value once.  `tri_b` is the C++ expression of b (b + 1) / 2."""
 
-    def __init__(self, n, compact_layout=None):
-        self.n, self.L = n, compact_layout
+    def __init__(self, n, compact_layout=None, blocks=False):
+        self.n, self.L, self.blocks = n, compact_layout, blocks
+
+    def _blk(self, t, i, a, b, val):  # blocks: the item's component has size cs, cube cs3 and index base cb (= BASE - c0 (cs^2 + cs + 1))
+        return "so[cb + %d*cs3 + ((%s)*cs + (%s))*cs + (%s)] = %s;" % (t, i, a, b, val)
 
     def sym(self, tensor, i, a, b, tri_b, val):  # d2tau_dq2 / d2tau_dqd2 entry (i; a, b) = (i; b, a), a <= b
         n = self.n
+        if self.blocks:
+            t = 0 if tensor == "q2" else 1
+            return self._blk(t, i, a, b, val) + " " + self._blk(t, i, b, a, val)
         if self.L is not None:
             return "so[%d + (%s)*%d + (%s) + (%s)] = %s;" % (self.L["Q2" if tensor == "q2" else "QD2"], i, self.L["TRI"], tri_b, a, val)
         base = 0 if tensor == "q2" else n ** 3
@@ -316,22 +372,26 @@ class _SoStores:
 
     def vq(self, i, a, b, val):
         n = self.n
+        if self.blocks:
+            return self._blk(2, i, a, b, val)
         return "so[%d + ((%s)*%d + (%s))*%d + (%s)] = %s;" % (self.L["VQ"] if self.L is not None else 2 * n ** 3, i, n, a, n, b, val)
 
     def mq(self, i, j, k, tri_k, val):  # dM_dq entry [i][j][k] = [k][j][i] = d M_ik / d q_j, i <= k
         n = self.n
+        if self.blocks:
+            return self._blk(3, i, j, k, val) + " " + self._blk(3, k, j, i, val)
         if self.L is not None:
             return "so[%d + ((%s) + (%s))*%d + (%s)] = %s;" % (self.L["MQ"], tri_k, i, n, j, val)
         return "so[%d + ((%s)*%d + (%s))*%d + (%s)] = so[%d + ((%s)*%d + (%s))*%d + (%s)] = %s;" % (3 * n ** 3, i, n, j, n, k, 3 * n ** 3, k, n, j, n, i, val)
 
 
-def _so_emit_balanced_main_dots(self, tree, compact, local=False):
+def _so_emit_balanced_main_dots(self, tree, compact, local=False, blocks=False):
     has_pris = any(s_ >= 3 for s_ in self.model.S_index)
     """Main loops, balanced mapping (gen_idsva_so_items), dot-product form (see _SO_FOLD); expects the per-lane quantities of _SO_PREP (lane <-> joint) and
     the records [S | Pd | Pdd | parent] in s_X.  Writes through `so`: the dense record (LDS or global memory) or the compact staging record."""
     n, G = self.model.n, self.lanes_per_solve
     table, slots, tA, tB = self.gen_idsva_so_items()
-    st = _SoStores(n, self.gen_idsva_so_compact_layout() if compact else None)
+    st = _SoStores(n, self.gen_idsva_so_chain_compact_layout() if compact else None, blocks=blocks)
     A = self.gen_add_code_line
     A("// balanced mapping: this lane's items (c, m), %d per lane, from the table grid_so_items (emitted with the model constants)" % slots)
     A("const bool own_lane = active@NOSTORE@;".replace("@NOSTORE@", " && (gravity < static_cast<T>(-1e30))" if self.tuning["debug_stop"] == 30 else ""))
@@ -344,6 +404,8 @@ def _so_emit_balanced_main_dots(self, tree, compact, local=False):
         A("const int ic = grid_so_items[%d*lane + %d], im = grid_so_items[%d*lane + %d];" % (2 * slots, 2 * sl, 2 * slots, 2 * sl + 1))
         A("const bool item = ic >= 0; const int c = item ? ic : 0, m = item ? im : 0; const bool own = own_lane && item;")
         A("const int tc = %s, tm = %s; (void)tc; (void)tm; // c (c + 1) / 2, m (m + 1) / 2: rows of the symmetric (compact) index" % (tri("c"), tri("m")))
+        if blocks:
+            A("const int cs = grid_so_blocks[3*c + 1], cs3 = cs*cs*cs, cb = grid_so_blocks[3*c + 2] - grid_so_blocks[3*c]*(cs*cs + cs + 1); // block of joint c's base-rooted component (every joint of the item lies in it)")
         A("T IC[10], BC[12], T1[6], T2[3], T3[6], T4[6], ICPd[6], S[6], Pd[6]; // joint c's quantities, fetched from its lane")
         for nm, ln_ in (("IC", 10), ("BC", 12), ("T1", 6), ("T2", 3), ("T3", 6), ("T4", 6), ("ICPd", 6), ("S", 6), ("Pd", 6)):
             A("#pragma unroll")
@@ -591,7 +653,7 @@ def _so_inner_header(self, compact=False):
                            "so = [d2tau_dq2 | d2tau_dqd2 | d2tau_dvdq | dM_dq], each n x n x n with [i][j][k] at i*n*n + j*n + k (reference algorithms/_idsva_so.py:204-208);",
                            "d2tau_dvdq[i][j][k] = d2 tau_i / dq_j dqd_k, dM_dq[i][j][k] = d M_ik / dq_j.  Every entry is written exactly once (trees: after a zero fill of the record by the same wave); `so` may be LDS" +
                            (" or global memory" if self.gen_idsva_so_mode() == "chain" else "")] +
-                          (["COMPACT form: `so` is the staging record of IDSVA_SO_STAGE_PER_SOLVE values that holds every value once (symmetric entries, no structural zeros); the dense",
+                          (["COMPACT form: `so` is the staging record of IDSVA_SO_STAGE_PER_SOLVE values (serial chains: every value once - symmetric entries, no structural zeros; trees: the dense blocks of the base-rooted components); the dense",
                             "record is gathered from it through the table grid_so_expand (what the kernels do when the record leaves for global memory)"] if compact else []),
                           [("so is the compact staging record of this solve (IDSVA_SO_STAGE_PER_SOLVE values)" if compact else "so is the output record of this solve (4*NUM_JOINTS^3 values)"), "s_qd is the vector of joint velocities in LDS",
                            "s_qdd is the vector of joint accelerations in LDS", "s_X is this solve's scratch: compact X(q) storage on entry; it is overwritten by the per-joint records",
@@ -715,7 +777,7 @@ def gen_idsva_so_local_origin(self):
     return self.gen_idsva_so_mode() == "tree" and self.tuning["so_origin"] == "joint" and self.tuning["so_mapping"] == "balanced" and self.tuning["so_loops"] == "dots"
 
 
-def gen_idsva_so_inner_tree(self, use_thread_group=False):
+def gen_idsva_so_inner_tree(self, use_thread_group=False, blocks=False):
     """Tree form.  Same operators and the same merged per-entry formulas as the chain form; what changes is where the per-joint quantities come from
     (level-by-level propagation through LDS instead of lane scans, all in the base frame) and which (m, l) pairs are visited: the reference's triples
     (joint j, ancestor-or-self an, subtree member c) live on ONE root path, so for every m only its subtree (a contiguous id range in DFS pre-order)
@@ -731,7 +793,7 @@ def gen_idsva_so_inner_tree(self, use_thread_group=False):
             self.gen_add_code_line(line)
         self.gen_add_code_line("")
         self._so_shift_lib_done = True
-    _so_inner_header(self)
+    _so_inner_header(self, compact=blocks)
     A = self.gen_add_code_line
     A("const int *tp = &grid_so_tree_topology[%d*lane]; // this lane's row: parent, level, subtree size, number of children, children" % K)
     A("const int par = tp[0], lev = tp[1];")
@@ -754,7 +816,9 @@ def gen_idsva_so_inner_tree(self, use_thread_group=False):
         A("  if (pris) { Lc[12] = r0; Lc[13] = r1; Lc[14] = r2; } }")
     self.gen_add_sync(use_thread_group)
     A("// zero fill of the output record: most of its 4 n^3 entries are structural zeros of the tree (joints on different root paths)")
-    if len(m_.roots) > 1:
+    if blocks:
+        A("if (active) { for (int e = lane; e < %d; e += GRID_LANES_PER_SOLVE) { so[e] = static_cast<T>(0); } } // (the component blocks and the ZERO slot that everything else expands from)" % self.gen_idsva_so_blocks_layout()["SIZE"])
+    elif len(m_.roots) > 1:
         A("if (active && blocks_only) { // (what fdsva_so_contract_kernel reads: the blocks of the base-rooted components; rows of `size` contiguous entries)", True)
         for r_ in m_.roots:
             c0, cs = r_, len(m_.subtree[r_])
@@ -881,7 +945,7 @@ def gen_idsva_so_inner_tree(self, use_thread_group=False):
              ("\n    rec[0] = wax[0]; rec[1] = wax[1]; rec[2] = wax[2]; rec[19] = pris ? static_cast<T>(1) : static_cast<T>(0); // (axis and joint type: a prismatic joint's S is [0; axis])" if has_pris else ""))
     if self.tuning["so_mapping"] == "balanced":
         if self.tuning["so_loops"] == "dots":
-            _so_emit_balanced_main_dots(self, tree=True, compact=False, local=local)
+            _so_emit_balanced_main_dots(self, tree=True, compact=False, local=local, blocks=blocks)
         else:
             _so_emit_balanced_main(self, tree=True)
         self.gen_add_end_function()
@@ -957,7 +1021,7 @@ def gen_idsva_so_kernel(self, use_thread_group=False, use_qdd_input=False, singl
     self.gen_kernel_prologue("IDSVA_SO_LDS_PER_SOLVE", "IDSVA_SO_MAX_SOLVES_PER_BLOCK")
     self.gen_add_code_line("T *s_q_qd_u = s_mem; T *s_q = s_q_qd_u; T *s_qd = &s_q_qd_u[%d]; T *s_qdd = &s_q_qd_u[%d]; T *s_scratch = &s_mem[%d]; (void)s_qdd;" % (n, 2 * n, pad3n))
     direct = self.gen_idsva_so_direct()
-    compact = self.gen_idsva_so_compact()
+    compact = self.gen_idsva_so_packed()
     if not direct:
         self.gen_add_code_line("T *s_idsva_so = &s_out_all[grp*%d]; // this solve's output record, staged in LDS%s" % (stage, " in compact form (every value once)" if compact else ""))
     if single_call_timing:
@@ -1052,7 +1116,7 @@ def gen_idsva_so(self, use_thread_group=False):
     self.gen_idsva_so_inner(use_thread_group, True)
     self.gen_idsva_so_device(use_thread_group, False)
     self.gen_idsva_so_device(use_thread_group, True)
-    if self.gen_idsva_so_compact():  # what the kernels run; the dense-record functions above stay for callers that hand in a record of their own
+    if self.gen_idsva_so_packed():  # what the kernels run; the dense-record functions above stay for callers that hand in a record of their own
         self.gen_idsva_so_inner(use_thread_group, True, compact=True)
         self.gen_idsva_so_device(use_thread_group, False, compact=True)
         self.gen_idsva_so_device(use_thread_group, True, compact=True)

@@ -162,7 +162,11 @@ def gen_model_constant_table(self):
         flat, _ = self.gen_fdsva_so_components()
         self.gen_add_code_line("// base-rooted component of every joint: first joint, size (algorithms/_fdsva_so.py: the contraction of fdsva_so is block diagonal over the components)")
         self.gen_add_code_line("__device__ const int grid_so_component[%d] = {%s};" % (len(flat), ", ".join(str(int(x)) for x in flat)))
-    if self.gen_idsva_so_mode() is not None and self.gen_idsva_so_compact():
+    if self.gen_idsva_so_mode() is not None and self.gen_idsva_so_blocks():
+        Lb = self.gen_idsva_so_blocks_layout()
+        self.gen_add_code_line("// block staging of the second-order record: first joint, size and block base of every joint's base-rooted component (algorithms/_idsva_so.py: gen_idsva_so_blocks_layout)")
+        self.gen_add_code_line("__device__ const int grid_so_blocks[%d] = {%s};" % (len(Lb["JOINTS"]), ", ".join(str(int(x)) for x in Lb["JOINTS"])))
+    if self.gen_idsva_so_mode() is not None and self.gen_idsva_so_packed():
         L = self.gen_idsva_so_compact_layout()
         self.gen_add_code_line("// slot of every element of the dense second-order record in the compact staging record (algorithms/_idsva_so.py: gen_idsva_so_compact_layout)")
         self.gen_add_code_line("__device__ __attribute__((aligned(16))) const unsigned short grid_so_expand[%d] = {%s};" % (len(L["TABLE"]), ", ".join(str(int(x)) for x in L["TABLE"])))
