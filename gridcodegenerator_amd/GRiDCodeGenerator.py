@@ -58,6 +58,7 @@ TUNING_DEFAULTS = {
     "stream_out": "auto",       # auto | True | False: forward_dynamics_gradient kernel of branch-frame robots stages ONE half of the record in LDS at a time
                                 # (dc/dqd columns parked compactly while dc/dq is assembled, both solved together, stored half after half);
                                 # auto = where that raises the resident waves per CU (the 30-DoF humanoid: 7 -> 8)
+    "branch_walk": "auto",      # path | owner | auto: entries of the branch-frame path - every lane walks its root path with running sums, or dot products in the frame of the ancestor's branch with the owner's vectors fetched across lanes (algorithms/_branch_frame_gradient.branch_owner_walk)
     "branch_chain": "auto",     # auto | walk | scan: frames of the branch-frame path - every lane walks its root path (D steps), or a log-step scan of rigid transforms
                                 # over the lanes of a branch + re-expression of the ancestors' joint axes level by level (algorithms/_branch_frame_gradient.py)
     "factor_split": "auto",     # auto | branch | component: who eliminates which pivots of the tree-sparse factorisation on the branch-frame path

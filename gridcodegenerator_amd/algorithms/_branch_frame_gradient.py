@@ -100,7 +100,9 @@ def gen_branch_frame_plan(self):
         shape_of[cb] = shapes.index(sig)
     D = max(len(p_) for p_ in paths)
     maxchild = max([len(k_) for k_ in kids] + [0])
-    row_len = (24 + D + max(maxchild, 1) + 3 * D + 3) // 4 * 4 + 4  # (header | path codes | child branches | joint offsets along the path | parent branch slot, pad)
+    ncross = len(set(i for p_ in paths for i in range(1, len(p_)) if br[p_[i]] != br[p_[i - 1]]))  # path steps at which some root path enters a parent branch
+    owner = branch_owner_walk(self, D, max(level), ncross)
+    row_len = (24 + D + max(maxchild, 1) + 3 * D + (D if owner else 0) + 3) // 4 * 4 + 4  # (header | path codes | child branches | joint offsets along the path | [lanes of the path joints] | parent branch slot, lane of the parent link, pad)
     # compact (tree-sparse) storage of M and of its factors: column k holds the entries of its ancestors (ascending) and then the diagonal
     mstart, at = [0] * n, 0
     for j in range(n):
@@ -114,7 +116,7 @@ def gen_branch_frame_plan(self):
     # branch-free stores), then for the factors and the branch hand-over records as far as they fit; what does not goes behind the path axes
     if nnz + 4 > 20 * n:
         return None
-    place, x_at, sp_at = {"M": ("x", 0), "trash": ("x", nnz)}, nnz + 4, 6 * D * nb
+    place, x_at, sp_at = {"M": ("x", 0), "trash": ("x", nnz)}, nnz + 4, (0 if owner else 6 * D * nb)  # (owner walk: no path records at all)
     for item, size in (("U", nnz), ("G", 28 * nb)):
         if x_at + size <= 20 * n:
             place[item] = ("x", x_at)
@@ -125,8 +127,8 @@ def gen_branch_frame_plan(self):
     # one spare set of path records at the very end takes the (branch-free) stores of the lanes that are not the first of their branch; the
     # kernels that have a result image in LDS send those stores to the head of the image instead (it is cleared after the frame chain), so
     # the forward-dynamics-gradient kernel does not carry the spare set in its LDS slice
-    sp_spare, sp_at = sp_at, sp_at + 6 * D
-    return dict(sp_spare=sp_spare, branches=branches, br=br, pb=pb, level=level, paths=paths, joint_of_lane=joint_of_lane, kids=kids, comp_base=comp_base,
+    sp_spare, sp_at = sp_at, sp_at + (0 if owner else 6 * D)
+    return dict(owner=owner, sp_spare=sp_spare, branches=branches, br=br, pb=pb, level=level, paths=paths, joint_of_lane=joint_of_lane, kids=kids, comp_base=comp_base,
                 shapes=shapes, shape_of=shape_of, D=D, maxLb=max(len(J) for J in branches), maxlevel=max(level), maxchild=maxchild, row_len=row_len, nb=nb, ubase=ubase, mstart=mstart, nnz=nnz, place=place, sp_size=sp_at, factor_work=factor_work)
 
 
@@ -134,7 +136,32 @@ def branch_spare_in_image(self, image_len):
     """The lanes that are not the first of their branch send their (branch-free) path-record stores of the frame chain to the head of the
     kernel's result image when that is large enough and one quad per lane clears it again; else to a spare set of records in s_SP."""
     D = self.branch_plan["D"]
+    if self.branch_plan["owner"]:
+        return False  # (no path records, no spare set)
     return image_len >= 6 * D and (6 * D + 3) // 4 <= self.lanes_per_solve
+
+
+def branch_owner_walk(self, D=None, maxlevel=None, ncross=0):
+    """tuning branch_walk: path | owner | auto.  path = every lane walks the root path of its branch and re-derives the ancestors' S_i, Pd_i, Pdd_i in ITS
+    branch frame by running sums (no cross-lane traffic, D steps of ~70 instructions, the joint axes of every path parked in LDS).  owner = every lane
+    keeps S, Pd, Pdd of its own joint in its own branch frame (velocities and accelerations by prefix scans inside the branch plus one hand-down per tree
+    level), the entries that couple joint k with an ancestor i are dot products in the frame of i's branch: lane k fetches the owner's vectors with
+    cross-lane reads (ds_bpermute) and re-expresses ITS t-vectors once per branch crossing; frames by the transform scan; no path records in LDS."""
+    want = self.tuning["branch_walk"]
+    if want not in ("path", "owner", "auto"):
+        raise ValueError("tuning['branch_walk'] must be path, owner or auto")
+    if D is None:
+        return self.branch_plan["owner"]
+    if want != "auto":
+        return want == "owner"
+    # instructions a wave spends on the ancestors, per path step and phase (static counts of the 30-DoF humanoid, tools/isa_stats.py): the path walk
+    # pays ~110 per step in its walks and ~80 in the frame chain (which the long single chains already replaced by the scan); the owner walk ~48
+    # per step plus the scan, the hand-downs per tree level and the re-expression of the t-vectors per crossing step.  Measured per 16 384 solves
+    # (profiles/ab/r3_owner_walk.jsonl): humanoid (D 10, two levels) 87.1 -> 77.5 us, 12-joint chain (D 12) 39.1 -> 34.2, 12-DoF tree (D 6, three levels) 30.8 -> 34.2
+    scan_default = maxlevel == 0 and D >= 10
+    path_cost = D * (110 + (0 if scan_default else 80))
+    owner_cost = 280 + 110 * maxlevel + 105 * ncross + 48 * D
+    return 1.15 * owner_cost < path_cost
 
 
 def branch_factor_by_branch(self):
@@ -261,7 +288,7 @@ def branch_chain_scan(self):
     return want == "scan" or (want == "auto" and P["maxlevel"] == 0 and P["D"] >= 10)
 
 
-def _emit_chain_scan(self, P, H, RL, bfam, kin, use_thread_group, ptr):
+def _emit_chain_scan(self, P, H, RL, bfam, kin, use_thread_group, ptr, owner=False):
     """Frames of the branch-frame path without the per-lane walk (tuning branch_chain = scan): a log-step DPP scan of rigid transforms over the lanes of a
     branch gives every lane the pose of its own link in the branch frame; the pose of the parent branch's frame follows from the branch's first lane;
     the joint axes along the root path are written by the lanes that own them and, tree level by tree level, re-expressed by the child branches (one
@@ -278,7 +305,8 @@ def _emit_chain_scan(self, P, H, RL, bfam, kin, use_thread_group, ptr):
     A("for (int r = 0; r < 9; r++) { Eo[r] = s_X[GRID_X_STRIDE*js + r]; En[r] = s_X[GRID_X_STRIDE*jn + r]; }")
     A("#pragma unroll")
     A("for (int r = 0; r < 3; r++) { ro_[r] = d_L[%d + 3*io + r]; rn_[r] = d_L[%d + 3*inx + r]; }" % (ro, ro))
-    A("const int pslot = static_cast<int>(d_L[%d]); // slot of the parent branch" % (RL - 4))
+    if not owner:
+        A("const int pslot = static_cast<int>(d_L[%d]); // slot of the parent branch" % (RL - 4))
     self.gen_add_sync(use_thread_group)
     A("// (every lane has read X(q): its storage is free from here on)  pose of this link relative to the next one: (E_next, -E_next r_next); identity on tip lanes")
     A("T R[9], p[3];")
@@ -329,6 +357,13 @@ def _emit_chain_scan(self, P, H, RL, bfam, kin, use_thread_group, ptr):
         A("{ const int lB = (active && iB >= 0) ? l0 + Lb - 1 - iB : lane; // the lane of the branch's middle joint")
         A("  pB[0] = grid_group_shfl(myp[0], lB); pB[1] = grid_group_shfl(myp[1], lB); pB[2] = grid_group_shfl(myp[2], lB);")
         A("  if (!(active && iB >= 0)) { pB[0] = pB[1] = pB[2] = Z; } }")
+    if owner:  # no path records: the entries are evaluated in the frames of the ancestors' branches (branch_owner_walk)
+        if kin:
+            A("if (level == 0) { gvec[0] = gravity*TR[2]; gvec[1] = gravity*TR[5]; gvec[2] = gravity*TR[8]; } // base acceleration (0,0,g) in the coordinates of a branch that hangs off the base (deeper branches receive it with the parent link's acceleration)")
+        else:
+            A("(void)gvec;")
+        self.gen_add_end_control_flow()
+        return
     A("T *s_Gh = %s; // branch records: free until the composites are handed over (here: gravity direction per branch)" % ptr("G"))
     A("(void)s_Gh; (void)pslot;")
     for lv in range(maxlevel + 1):
@@ -389,6 +424,10 @@ def gen_branch_frame_constants(self):
                 row[24 + i] = -1.0
             for c in range(max(P["maxchild"], 1)):
                 row[24 + P["D"] + c] = -1.0
+            if P["owner"]:
+                for i in range(P["D"]):
+                    row[24 + P["D"] + max(P["maxchild"], 1) + 3 * P["D"] + i] = -1.0
+                row[P["row_len"] - 3] = -1.0
             rows += row
             continue
         I = m.I[j]
@@ -419,6 +458,12 @@ def gen_branch_frame_constants(self):
         for i, pj in enumerate(P["paths"][b]):
             r = self.gen_tip_frame_joint_offset(pj)
             row[ro + 3 * i:ro + 3 * i + 3] = [float(r[0]), float(r[1]), float(r[2])]
+        if P["owner"]:  # lane that owns every path joint (+64: the path enters the parent branch here), lane of the link the branch hangs off
+            lane_of = {jj: ll for ll, jj in enumerate(P["joint_of_lane"]) if jj >= 0}
+            path = P["paths"][b]
+            for i in range(P["D"]):
+                row[ro + 3 * P["D"] + i] = float(lane_of[path[i]] + (64 if (i > 0 and P["br"][path[i]] != P["br"][path[i - 1]]) else 0)) if i < len(path) else -1.0
+            row[P["row_len"] - 3] = float(lane_of[path[len(J)]]) if len(path) > len(J) else -1.0
         row[P["row_len"] - 4] = float(P["pb"][b])  # slot of the parent branch (-1: the branch hangs off the base)
         rows += row
     return rows
@@ -457,6 +502,13 @@ template <typename T>
 __device__ __forceinline__ void grid_force_up(T *y, const T (&R)[9], const T (&p)[3], const T (&f)[6]) {
     grid_rt3(y, R, f[0] - (p[1]*f[5] - p[2]*f[4]), f[1] - (p[2]*f[3] - p[0]*f[5]), f[2] - (p[0]*f[4] - p[1]*f[3]));
     grid_rt3(y + 3, R, f[3], f[4], f[5]);
+}
+// motion vector [w; v_O] given in the parent's frame (about its origin) -> in the branch frame (about its origin): w' = R w, v' = R v_O + p x w'
+template <typename T>
+__device__ __forceinline__ void grid_motion_down(T (&y)[6], const T (&R)[9], const T (&p)[3], const T (&x)[6]) {
+    #pragma unroll
+    for (int r = 0; r < 3; r++) { y[r] = R[3*r]*x[0] + R[3*r + 1]*x[1] + R[3*r + 2]*x[2]; y[3 + r] = R[3*r]*x[3] + R[3*r + 1]*x[4] + R[3*r + 2]*x[5]; }
+    y[3] += p[1]*y[2] - p[2]*y[1]; y[4] += p[2]*y[0] - p[0]*y[2]; y[5] += p[0]*y[1] - p[1]*y[0];
 }
 // composite inertia (10) of a whole branch, re-expressed in the parent branch's frame: origin shift (c' = c - p), then rotation
 template <typename T>
@@ -513,6 +565,10 @@ _MKJ_FAM = ("(Spi[0]*t1m[0] + Spi[1]*t1m[1] + Spi[2]*t1m[2]"
             " + (fam ? Spi[3] - (pB[1]*Spi[2] - pB[2]*Spi[1]) : Spi[3])*t1m[3]"
             " + (fam ? Spi[4] - (pB[2]*Spi[0] - pB[0]*Spi[2]) : Spi[4])*t1m[4]"
             " + (fam ? Spi[5] - (pB[0]*Spi[1] - pB[1]*Spi[0]) : Spi[5])*t1m[5])")
+
+
+# owner walk: S_i about pB dotted with t1m = S_i (about the frame origin) dotted with t1m moved from pB to the origin: n + pB x f - once instead of a cross product per path step
+_FAM_FOLD = "if (fam) { w1m[0] += pB[1]*w1m[5] - pB[2]*w1m[4]; w1m[1] += pB[2]*w1m[3] - pB[0]*w1m[5]; w1m[2] += pB[0]*w1m[4] - pB[1]*w1m[3]; }"
 
 
 def _t1m_lines():
@@ -638,7 +694,16 @@ def _emit_branch_inner(self, mode, use_thread_group=False):
     if bfam:
         A("const int iB = static_cast<int>(d_L[22]); const bool fam = d_L[23] > static_cast<T>(0.5); // base-origin family of the joint-space inertia (leaf branches of >= 5 joints)")
     A("const int li = jid - cbase;   // index of the joint inside its base-rooted component")
-    A("T *s_Sp = &s_SP[%d*slot]; // joint axes along the root path of this lane's branch, in the branch frame" % (6 * D))
+    owner = P["owner"]
+    if owner:
+        PL = H + D + max(maxchild, 1) + 3 * D
+        for i in range(D):
+            A("const int plc%d = static_cast<int>(d_L[%d]); const int pl%d = (plc%d >= 0) ? (plc%d & 63) : lane; const bool cr%d = plc%d >= 64; // lane that owns path joint %d; the path enters the parent branch here"
+              % (i, PL + i, i, i, i, i, i, i))
+        A("const int lparc = static_cast<int>(d_L[%d]); const int lpar = (lparc >= 0) ? lparc : lane; // lane of the link this lane's branch hangs off" % (RL - 3))
+        A("(void)s_SP; (void)lpar;" + "".join(" (void)pl%d; (void)cr%d;" % (i, i) for i in range(D)))
+    else:
+        A("T *s_Sp = &s_SP[%d*slot]; // joint axes along the root path of this lane's branch, in the branch frame" % (6 * D))
     A("(void)level; (void)plen; (void)s_G; (void)mstart; (void)s_Mc; (void)s_Uc; (void)s_trash; (void)shape; (void)li; (void)ubase;")
     for i in range(D):
         A("const int pc%d = static_cast<int>(d_L[%d]); const bool pv%d = pc%d >= 0; const int pj%d = pv%d ? (pc%d >> 2) : js; const bool act%d = pv%d && (%d >= own);"
@@ -646,13 +711,19 @@ def _emit_branch_inner(self, mode, use_thread_group=False):
     zero = {"fdgrad": ("s_df_du", n * n if stream else 2 * n * n), "idgrad": ("s_dc_du", 2 * n * n), "minv": ("s_Minv", n * ld)}.get(mode)
     A("grid_wave_sync();")
     spare_in_image = zero is not None and branch_spare_in_image(self, zero[1])
-    lanes_head = (6 * D + 3) // 4 if (spare_in_image and not branch_chain_scan(self)) else 0  # quads at the head of the image that take the spare path records of the frame chain
+    lanes_head = (6 * D + 3) // 4 if (spare_in_image and not branch_chain_scan(self) and not owner) else 0  # quads at the head of the image that take the spare path records of the frame chain
     if zero is not None:
         A("// zero image of the result (unrelated joints, and rows outside the component of a column, stay exactly zero)")
         A("for (int e = lane + %d; e < %d; e += %d) {" % (lanes_head, zero[1] // 4, lanes), True)
         A("#pragma unroll")
         A("for (int r = 0; r < 4; r++) { %s[4*e + r] = Z; }" % zero[0])
         self.gen_add_end_control_flow()
+        if stream and owner:
+            ylen = (n * max(len(s_) for s_ in P["shapes"]) + 3) // 4
+            A("for (int e = lane; e < %d; e += %d) { // ... and of the parked d/dqd columns (pass 2 writes their entries directly)" % (ylen, lanes), True)
+            A("#pragma unroll")
+            A("for (int r = 0; r < 4; r++) { s_Y[4*e + r] = Z; }")
+            self.gen_add_end_control_flow()
         if zero[1] % 4:  # (never past the end of the image: the next lane group's image starts there)
             A("if (lane < %d) { %s[%d + lane] = Z; }" % (zero[1] % 4, zero[0], zero[1] // 4 * 4))
     # ------------------------------------------------------------------ frame chain along the root path
@@ -663,9 +734,9 @@ def _emit_branch_inner(self, mode, use_thread_group=False):
     A("T myR[9], myp[3], TR[9], Tp[3], gvec[3] = {Z, Z, Z};")
     if bfam:
         A("T pB[3] = {Z, Z, Z}; // second reference point: the frame origin of the branch's middle joint, in the branch frame")
-    chain_scan = branch_chain_scan(self)
+    chain_scan = owner or branch_chain_scan(self)
     if chain_scan:
-        _emit_chain_scan(self, P, H, RL, bfam, kin, use_thread_group, ptr)
+        _emit_chain_scan(self, P, H, RL, bfam, kin, use_thread_group, ptr, owner)
     else:
         A("{", True)
         ro = H + D + max(maxchild, 1)
@@ -821,7 +892,86 @@ def _emit_branch_inner(self, mode, use_thread_group=False):
         A("GRID_SCHED_FENCE();")
         self.gen_add_end_control_flow()
 
-    if kin:
+    def hand_down(name, what):
+        """owner walk: the lanes of tree level lv add the parent link's `name` (final after level lv - 1), re-expressed in their branch frame"""
+        for lv in range(1, maxlevel + 1):
+            A("{ // tree level %d: %s of the link the branch hangs off, in this branch's frame" % (lv, what), True)
+            A("T xi[6], y[6];")
+            A("#pragma unroll")
+            A("for (int r = 0; r < 6; r++) { xi[r] = grid_group_shfl(%s[r], lpar); }" % name)
+            A("grid_motion_down(y, TR, Tp, xi);")
+            A("if (level == %d) {" % lv, True)
+            A("#pragma unroll")
+            A("for (int r = 0; r < 6; r++) { %s[r] += y[r]; }" % name)
+            self.gen_add_end_control_flow()
+            self.gen_add_end_control_flow()
+
+    cross_steps = sorted(set(i for b in range(P["nb"]) for i in range(1, len(P["paths"][b])) if P["br"][P["paths"][b][i]] != P["br"][P["paths"][b][i - 1]]))
+
+    def owner_walk(fetch, fvecs, cvecs, body):
+        """owner walk along the root path, tip -> root: per step the owner's vectors (`fetch`: S, Pd, Pdd of path joint i in the frame of ITS branch) arrive by
+        cross-lane reads, one step ahead of their use; where the path enters the parent branch (cr_i) the lane's force-type vectors `fvecs` and the couples
+        `cvecs` (3 values, no linear part) are re-expressed in the parent branch's frame."""
+        loc = {"S": "Spi", "Pd": "Pdi", "Pdd": "Pddi"}
+        nxt = {"S": "Sn", "Pd": "Pdn", "Pdd": "Pddn"}
+        A("T " + ", ".join("%s[6]" % nxt[f] for f in fetch) + ";")
+
+        def fetch_step(i):
+            for f in fetch:
+                A("#pragma unroll")
+                A("for (int r = 0; r < 6; r++) { %s[r] = grid_group_shfl(%s[r], pl%d); }" % (nxt[f], f, i))
+
+        fetch_step(0)
+        for i in range(D):
+            if i in cross_steps:
+                A("{ // the root paths of some branches enter their parent branch at step %d: their vectors move into that branch's frame" % i, True)
+                if maxlevel > 1:
+                    A("T R_[9], p_[3]; // pose of the next frame in the current one: TR, Tp of the lanes of the branch that ends here")
+                    A("#pragma unroll")
+                    A("for (int r = 0; r < 9; r++) { R_[r] = grid_group_shfl(TR[r], pl%d); }" % (i - 1))
+                    A("#pragma unroll")
+                    A("for (int r = 0; r < 3; r++) { p_[r] = grid_group_shfl(Tp[r], pl%d); }" % (i - 1))
+                else:
+                    A("const T (&R_)[9] = TR; const T (&p_)[3] = Tp;")
+                A("if (cr%d) {" % i, True)
+                for f in fvecs:
+                    A("{ T y[6]; grid_force_up(y, R_, p_, %s);" % f)
+                    A("  #pragma unroll")
+                    A("  for (int r = 0; r < 6; r++) { %s[r] = y[r]; } }" % f)
+                for c in cvecs:
+                    A("{ T y[3]; grid_rt3(y, R_, %s[0], %s[1], %s[2]); %s[0] = y[0]; %s[1] = y[1]; %s[2] = y[2]; }" % (c, c, c, c, c, c))
+                self.gen_add_end_control_flow()
+                self.gen_add_end_control_flow()
+            A("{ // path step %d" % i, True)
+            A("T " + ", ".join("%s[6]" % loc[f] for f in fetch) + ";")
+            A("#pragma unroll")
+            A("for (int r = 0; r < 6; r++) { " + " ".join("%s[r] = %s[r];" % (loc[f], nxt[f]) for f in fetch) + " }")
+            if i < D - 1:
+                fetch_step(i + 1)
+            body(i)
+            A("GRID_SCHED_FENCE();")
+            self.gen_add_end_control_flow()
+
+    if kin and owner:
+        A("T mku[GRID_SCAN_STEPS]; // prefix masks: the partner lane of step s is a joint of the same branch")
+        if not steps:
+            A("mku[0] = Z;")
+        for s_, k in enumerate(steps):
+            A("mku[%d] = (pos >= %d) ? static_cast<T>(1) : Z;" % (s_, k))
+        A("T v[6], a[6];")
+        A("#pragma unroll")
+        A("for (int r = 0; r < 6; r++) { v[r] = S[r]*qd; }")
+        A("grid_prefix_sum(v, mku); // joints of the own branch up to this one")
+        hand_down("v", "velocity")
+        A("T Pd[6]; grid_mxm(Pd, v, S); // = S-dot of the own joint")
+        if qdd_in:
+            A("const T qddo = %s;" % ("(active && s_qddin != nullptr) ? s_qddin[js] : Z" if mode == "id" else "active ? s_qddin[js] : Z"))
+        A("#pragma unroll")
+        A("for (int r = 0; r < 6; r++) { a[r] = Pd[r]*qd%s; }" % (" + S[r]*qddo" if qdd_in else ""))
+        A("grid_prefix_sum(a, mku);")
+        A("a[3] += gvec[0]; a[4] += gvec[1]; a[5] += gvec[2]; // (zero below tree level 0)")
+        hand_down("a", "acceleration")
+    elif kin:
         A("T v[6] = {Z, Z, Z, Z, Z, Z}, a[6] = {Z, Z, Z, Z, Z, Z};")
         A("{", True)
         walk_open(qdd_in)
@@ -932,6 +1082,22 @@ def _emit_branch_inner(self, mode, use_thread_group=False):
         A("grid_bmul(t2, BC, S); grid_rbi_mul_peq(t2, IC, Pd, static_cast<T>(2));")
         A("grid_bmul(t3, BC, Pd); grid_rbi_mul_peq(t3, IC, Pdd, static_cast<T>(1)); grid_fxv_peq(t3, S, fC);")
         A("grid_btmul(t4, BC, S);")
+        if owner:
+            A("{", True)
+
+            def body(i):
+                A("const T up_q = grid_dot6(Spi, t3), up_d = grid_dot6(Spi, t2);")
+                A("const T lo_q = grid_dot6(t1, Pddi) + t4[0]*Pdi[0] + t4[1]*Pdi[1] + t4[2]*Pdi[2];")
+                A("const T lo_d = static_cast<T>(2)*grid_dot6(t1, Pdi) + t4[0]*Spi[0] + t4[1]*Spi[1] + t4[2]*Spi[2];")
+                A("*(act%d ? &s_dc_du[jid*%d + pj%d] : s_trash) = up_q;" % (i, n, i))
+                A("*(act%d ? &s_dc_du[(%d + jid)*%d + pj%d] : s_trash) = up_d + ((own == %d) ? damping : Z); // + damping on the diagonal (oracle _test.py:486)" % (i, n, n, i, i))
+                A("*((act%d && own != %d) ? &s_dc_du[pj%d*%d + jid] : s_trash) = lo_q;" % (i, i, i, n))
+                A("*((act%d && own != %d) ? &s_dc_du[(%d + pj%d)*%d + jid] : s_trash) = lo_d;" % (i, i, n, i, n))
+
+            owner_walk(("S", "Pd", "Pdd"), ("t1", "t2", "t3"), ("t4",), body)
+            self.gen_add_end_control_flow()
+            self.gen_add_end_function()
+            return
         A("{", True)
         A("T vr[6] = {Z, Z, Z, Z, Z, Z}, ar[6] = {Z, Z, Z, gvec[0], gvec[1], gvec[2]};")
         walk_open(True)
@@ -974,10 +1140,20 @@ def _emit_branch_inner(self, mode, use_thread_group=False):
         _probe(self, "t1", "t1:6")
         A("if (active) { s_qdd[jid] = s_u[jid] - (grid_dot6(S, fC) + damping*qd); }")
         A("{", True)
-        A("T t2[6]; grid_bmul(t2, BC, S); grid_rbi_mul_peq(t2, IC, Pd, static_cast<T>(2));")
-        A("T vr[6] = {Z, Z, Z, Z, Z, Z};")
-        walk_open(False)
-        for i in range(D - 1, -1, -1):
+        if not owner:
+            A("T t2[6]; grid_bmul(t2, BC, S); grid_rbi_mul_peq(t2, IC, Pd, static_cast<T>(2));")
+        if owner:  # only the joint-space inertia here (the factorisation waits for it); the d/dqd entries join pass 2, which fetches Pd_i anyway
+            A("T w1m[6]; // (t1 stays in the branch frame for pass 2)")
+            A("#pragma unroll")
+            A("for (int r = 0; r < 6; r++) { w1m[r] = %s[r]; }" % ("t1m" if bfam else "t1"))
+            if bfam:
+                A(_FAM_FOLD)
+            owner_walk(("S",), ("w1m",), (), lambda i: A("*(act%d ? &s_Mc[mstart + plen - %d] : s_trash) = %s; // (ancestors in ascending order, then the diagonal)"
+                       % (i, i + 1, ("static_cast<T>(static_cast<float>(%s))" if "M" in tuple(self.tuning.get("round_probe", ())) else "%s") % "grid_dot6(Spi, w1m)")))
+        else:
+            A("T vr[6] = {Z, Z, Z, Z, Z, Z};")
+            walk_open(False)
+        for i in (() if owner else range(D - 1, -1, -1)):
             walk_step(i, False)
             A("T Pdi[6];")
             A("#pragma unroll")
@@ -1002,10 +1178,16 @@ def _emit_branch_inner(self, mode, use_thread_group=False):
         if mode == "fd":
             A("if (active) { s_qdd[jid] = s_u[jid] - (grid_dot6(S, fC) + damping*qd); }")
         A("{", True)
-        A("T Sn[6];")
-        A("#pragma unroll")
-        A("for (int r = 0; r < 6; r++) { Sn[r] = s_Sp[%d + r]; }" % (6 * (D - 1)))
-        for i in range(D - 1, -1, -1):
+        if owner:
+            A("T (&w1m)[6] = %s;" % ("t1m" if bfam else "t1"))
+            if bfam:
+                A(_FAM_FOLD)
+            owner_walk(("S",), ("w1m",), (), lambda i: A("*(act%d ? &s_Mc[mstart + plen - %d] : s_trash) = grid_dot6(Spi, w1m); // (ancestors in ascending order, then the diagonal)" % (i, i + 1)))
+        else:
+            A("T Sn[6];")
+            A("#pragma unroll")
+            A("for (int r = 0; r < 6; r++) { Sn[r] = s_Sp[%d + r]; }" % (6 * (D - 1)))
+        for i in (() if owner else range(D - 1, -1, -1)):
             A("{ T Spi[6];")
             A("  #pragma unroll")
             A("  for (int r = 0; r < 6; r++) { Spi[r] = Sn[r]; }")
@@ -1150,7 +1332,7 @@ def _emit_branch_inner(self, mode, use_thread_group=False):
         A("for (int e = 4*lane; e + 3 < %d; e += %d) { T tmp[4]; __builtin_memcpy(tmp, __builtin_assume_aligned(s_df_du + e, 4*sizeof(T) < 16 ? 4*sizeof(T) : 16), 4*sizeof(T)); grid_store4(d_df_du_k + %d + e, tmp); }" % (n * n, 4 * lanes, dst_off))
         self.gen_add_end_control_flow()
 
-    if stream:
+    if stream and not owner:
         A("// half-image form: pass 1 assembled dc/dqd in the image; every lane parks its own column (rows of its component), pass 2 then overwrites")
         A("// exactly the same entries with dc/dq (same index pattern), so the image needs no clearing in between")
         for si, sig in enumerate(shapes):
@@ -1164,15 +1346,22 @@ def _emit_branch_inner(self, mode, use_thread_group=False):
     A("// the acceleration-dependent parts: a += sum over the ancestors of S_i qdd_i, f^C += sum over the subtree of I_k da_k")
     A("{", True)
     A("T da[6] = {Z, Z, Z, Z, Z, Z}, Ida[6];")
-    A("{", True)
-    walk_open(True)
-    for i in range(D - 1, -1, -1):
-        walk_step(i, True)
-        A("#pragma unroll")
-        A("for (int r = 0; r < 6; r++) { da[r] += Spi[r]*qddi; }")
-        A("(void)qdi;")
-        walk_close()
-    self.gen_add_end_control_flow()
+    if owner:
+        A("{ const T qddo = active ? s_qdd[js] : Z;")
+        A("  #pragma unroll")
+        A("  for (int r = 0; r < 6; r++) { da[r] = S[r]*qddo; } }")
+        A("grid_prefix_sum(da, mku);")
+        hand_down("da", "the qdd part of the acceleration")
+    else:
+        A("{", True)
+        walk_open(True)
+        for i in range(D - 1, -1, -1):
+            walk_step(i, True)
+            A("#pragma unroll")
+            A("for (int r = 0; r < 6; r++) { da[r] += Spi[r]*qddi; }")
+            A("(void)qdi;")
+            walk_close()
+        self.gen_add_end_control_flow()
     A("grid_rbi_mul(Ida, I, da); grid_suffix_sum(Ida, mkd);")
     for lv in range(maxlevel, 0, -1):
         A("{ // tree level %d -> %d" % (lv, lv - 1), True)
@@ -1196,21 +1385,40 @@ def _emit_branch_inner(self, mode, use_thread_group=False):
     A("{", True)
     A("T Pdd[6]; grid_mxm(Pdd, a, S); grid_mxm_peq(Pdd, v, Pd);")
     A("T t3[6]; grid_bmul(t3, BC, Pd); grid_rbi_mul_peq(t3, IC, Pdd, static_cast<T>(1)); grid_fxv_peq(t3, S, fC);")
-    A("T vr[6] = {Z, Z, Z, Z, Z, Z}, ar[6] = {Z, Z, Z, gvec[0], gvec[1], gvec[2]};")
-    walk_open(True)
-    for i in range(D - 1, -1, -1):
-        walk_step(i, True)
-        A("T Pdi[6], Pddi[6];")
-        A("#pragma unroll")
-        A("for (int r = 0; r < 6; r++) { vr[r] += Spi[r]*qdi; }")
-        A("grid_mxm(Pdi, vr, Spi);")
-        A("#pragma unroll")
-        A("for (int r = 0; r < 6; r++) { ar[r] += Pdi[r]*qdi + Spi[r]*qddi; }")
-        A("grid_mxm(Pddi, ar, Spi); grid_mxm_peq(Pddi, vr, Pdi);")
-        A("const T up_q = grid_dot6(Spi, t3), lo_q = grid_dot6(t1, Pddi) + t4[0]*Pdi[0] + t4[1]*Pdi[1] + t4[2]*Pdi[2];")
-        A("*(act%d ? &s_df_du[jid*%d + pj%d] : s_trash) = up_q;" % (i, n, i))
-        A("*((act%d && own != %d) ? &s_df_du[pj%d*%d + jid] : s_trash) = lo_q;" % (i, i, i, n))
-        walk_close()
+    if owner:
+        A("T t2[6]; grid_bmul(t2, BC, S); grid_rbi_mul_peq(t2, IC, Pd, static_cast<T>(2));")
+        if stream:
+            A("// (half-image form: the d/dqd entries go straight into the parked columns - column-major, rows of the column's component only)")
+
+        def body(i):
+            A("const T up_q = grid_dot6(Spi, t3), lo_q = grid_dot6(t1, Pddi) + t4[0]*Pdi[0] + t4[1]*Pdi[1] + t4[2]*Pdi[2];")
+            A("const T up_d = grid_dot6(Spi, t2), lo_d = static_cast<T>(2)*grid_dot6(t1, Pdi) + t4[0]*Spi[0] + t4[1]*Spi[1] + t4[2]*Spi[2];")
+            A("*(act%d ? &s_df_du[jid*%d + pj%d] : s_trash) = up_q;" % (i, n, i))
+            A("*((act%d && own != %d) ? &s_df_du[pj%d*%d + jid] : s_trash) = lo_q;" % (i, i, i, n))
+            if stream:
+                A("*(act%d ? &s_Y[jid*%d + pj%d - cbase] : s_trash) = up_d + ((own == %d) ? damping : Z); // + damping on the diagonal (oracle _test.py:486)" % (i, NCmax, i, i))
+                A("*((act%d && own != %d) ? &s_Y[pj%d*%d + jid - cbase] : s_trash) = lo_d;" % (i, i, i, NCmax))
+            else:
+                A("*(act%d ? &s_df_du[(%d + jid)*%d + pj%d] : s_trash) = up_d + ((own == %d) ? damping : Z); // + damping on the diagonal (oracle _test.py:486)" % (i, n, n, i, i))
+                A("*((act%d && own != %d) ? &s_df_du[(%d + pj%d)*%d + jid] : s_trash) = lo_d;" % (i, i, n, i, n))
+
+        owner_walk(("S", "Pd", "Pdd"), ("t1", "t2", "t3"), ("t4",), body)
+    else:
+        A("T vr[6] = {Z, Z, Z, Z, Z, Z}, ar[6] = {Z, Z, Z, gvec[0], gvec[1], gvec[2]};")
+        walk_open(True)
+        for i in range(D - 1, -1, -1):
+            walk_step(i, True)
+            A("T Pdi[6], Pddi[6];")
+            A("#pragma unroll")
+            A("for (int r = 0; r < 6; r++) { vr[r] += Spi[r]*qdi; }")
+            A("grid_mxm(Pdi, vr, Spi);")
+            A("#pragma unroll")
+            A("for (int r = 0; r < 6; r++) { ar[r] += Pdi[r]*qdi + Spi[r]*qddi; }")
+            A("grid_mxm(Pddi, ar, Spi); grid_mxm_peq(Pddi, vr, Pdi);")
+            A("const T up_q = grid_dot6(Spi, t3), lo_q = grid_dot6(t1, Pddi) + t4[0]*Pdi[0] + t4[1]*Pdi[1] + t4[2]*Pdi[2];")
+            A("*(act%d ? &s_df_du[jid*%d + pj%d] : s_trash) = up_q;" % (i, n, i))
+            A("*((act%d && own != %d) ? &s_df_du[pj%d*%d + jid] : s_trash) = lo_q;" % (i, i, i, n))
+            walk_close()
     self.gen_add_end_control_flow()
     self.gen_add_sync(use_thread_group)
     # ------------------------------------------------------------------ column solves

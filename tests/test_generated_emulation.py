@@ -66,15 +66,17 @@ def test_emulated_one_column_per_lane_variant(name, golden):
                                       ("iiwa14", {"gradient_walk": "registers"}), ("iiwa14", {"tip_chain": "lds"}), ("arm6", {"gradient_walk": "registers"}),
                                       ("iiwa14", {"gradient_walk": "branch"}), ("hyq", {"gradient_walk": "branch"}),
                                       ("atlas", {"gradient_walk": "registers"}), ("tree12", {"stream_out": True}), ("tree12", {"factor_split": "branch"}), ("atlas", {"factor_split": "component"}),
-                                      ("hyq", {"gradient_walk": "branch", "factor_split": "branch"}), ("atlas", {"branch_chain": "scan"}), ("tree12", {"branch_chain": "scan"}),
-                                      ("chain12", {"branch_chain": "walk"})])
+                                      ("hyq", {"gradient_walk": "branch", "factor_split": "branch"}), ("atlas", {"branch_chain": "scan", "branch_walk": "path"}), ("tree12", {"branch_chain": "scan"}),
+                                      ("chain12", {"branch_chain": "walk", "branch_walk": "path"}), ("atlas", {"branch_walk": "path"}), ("tree12", {"branch_walk": "owner"}),
+                                      ("tree12", {"branch_walk": "owner", "stream_out": True})])
 def test_emulated_generation_variants(name, tuning, golden):
     """The non-default generated forms stay correct: LDS-assisted forward accumulation of the derivative walk (what deep trees get),
     RNEA re-use, unfused forward dynamics; the branch-frame path (default for branched revolute robots such as atlas) forced onto chains and
     forests (one branch / equal branches, 8- and 16-lane groups), the column walk forced onto atlas, and the branch-frame kernel that stages one half
     of the record at a time (stream_out: measured slower on the humanoid, kept as an option); the tree-sparse factorisation split by branch (default
     for the humanoid) forced onto the 12-DoF tree (three hand-over levels) and the quadruped, and the per-component form forced onto the humanoid; the scan form of
-    the frame chain (default for the 12-joint chain) forced onto the trees and the walk onto the chain."""
+    the frame chain (default for the 12-joint chain) forced onto the trees and the walk onto the chain; the owner walk (branch_walk: default for the humanoid and the
+    12-joint chain) forced onto the 12-DoF tree (three tree levels: two crossings per root path) and the path walk onto the humanoid."""
     g = golden(name)
     lib = emu_library(name, max_timesteps=64, tuning=dict({"so_lanes": "off"}, **tuning))  # (first-order checks only: no second library instance to compile)
     n = lib.n
