@@ -440,11 +440,14 @@ def _random_tree_description(seed, n):
 
 
 @pytest.mark.parametrize("seed,n,tuning", [(16, 8, {}), (13, 7, {}), (1, 9, {}), (4, 27, {}),  # (8-lane groups with two tree levels / two components, ..., 32-lane groups)
-                                           (58, 20, {"factor_split": "branch", "stream_out": True}), (61, 11, {"factor_split": "branch"})])  # (three / four tree levels)
+                                           (58, 20, {"factor_split": "branch", "stream_out": True}), (61, 11, {"factor_split": "branch"}),  # (three / four tree levels)
+                                           (58, 20, {"branch_walk": "owner", "stream_out": True}), (61, 11, {"branch_walk": "owner", "factor_split": "branch"}),  # (owner walk: up to three crossings per root path)
+                                           (4, 27, {"branch_walk": "owner"}), (16, 8, {"branch_walk": "owner"}), (4, 27, {"branch_walk": "path"})])
 def test_emulated_random_trees_on_the_branch_frame_path(seed, n, tuning):
     """Generator robustness: random tree topologies (nesting depth, component shapes, lane packing all vary) through the unchanged
     generated header on the branch-frame path, checked against the C oracle (itself pinned by the reference's goldens); the last cases force the
-    factorisation split by branch (Schur complements handed up over three and four tree levels) and the half-image form of the kernel."""
+    factorisation split by branch (Schur complements handed up over three and four tree levels) and the half-image form of the kernel; then the owner walk
+    (cross-lane reads of the owners' vectors, t-vectors re-expressed at every branch crossing) forced onto deep trees and the path walk onto a wide one."""
     from gridcodegenerator_amd import GRiDCodeGenerator
     from oracle.rbd_oracle import Oracle
 
@@ -483,13 +486,14 @@ def test_emulated_run_longer_than_a_dpp_row_is_split_into_branches():
     assert not GRiDCodeGenerator(robot).branch_frame
     plan = GRiDCodeGenerator(robot, tuning={"gradient_walk": "branch"}).branch_plan
     assert [len(b) for b in plan["branches"]] == [16, 4] and plan["level"] == [0, 1] and plan["place"]["U"][0] == "sp" and plan["factor_work"] == 1330
-    lib = emu_library(robot, max_timesteps=8, tuning={"gradient_walk": "branch"})
     n, N = 20, 3
     rng = np.random.default_rng(0)
     x = np.hstack([rng.uniform(-np.pi, np.pi, (N, n)), rng.uniform(-2, 2, (N, n)), rng.uniform(-10, 10, (N, n))]).astype(np.float32)
     ref, _ = Oracle(robot).fd_grad_batch(x.astype(np.float64))
-    lib.set_launch_dims(0, 64)
-    assert per_solve_err(lib.forward_dynamics_gradient_host(x), ref) <= TOL
+    for walk in ("path", "owner"):  # (owner walk: no path records, the factors are all that is left in s_SP)
+        lib = emu_library(robot, max_timesteps=8, tuning={"gradient_walk": "branch", "branch_walk": walk})
+        lib.set_launch_dims(0, 64)
+        assert per_solve_err(lib.forward_dynamics_gradient_host(x), ref) <= TOL, walk
 
 
 def test_emulated_debug_mode_dumps_the_rnea_intermediates_the_reference_prints(golden, capfd):
