@@ -59,6 +59,7 @@ TUNING_DEFAULTS = {
                                 # (dc/dqd columns parked compactly while dc/dq is assembled, both solved together, stored half after half);
                                 # auto = where that raises the resident waves per CU (the 30-DoF humanoid: 7 -> 8)
     "branch_walk": "auto",      # path | owner | auto: entries of the branch-frame path - every lane walks its root path with running sums, or dot products in the frame of the ancestor's branch with the owner's vectors fetched across lanes (algorithms/_branch_frame_gradient.branch_owner_walk)
+    "factor_preload": True,     # branch-frame path: the column solves read the factors of a component into registers with 16-byte LDS loads (False: one 4-byte read per use)
     "branch_chain": "auto",     # auto | walk | scan: frames of the branch-frame path - every lane walks its root path (D steps), or a log-step scan of rigid transforms
                                 # over the lanes of a branch + re-expression of the ancestors' joint axes level by level (algorithms/_branch_frame_gradient.py)
     "factor_split": "auto",     # auto | branch | component: who eliminates which pivots of the tree-sparse factorisation on the branch-frame path

@@ -104,10 +104,14 @@ def gen_branch_frame_plan(self):
     owner = branch_owner_walk(self, D, max(level), ncross)
     row_len = (24 + D + max(maxchild, 1) + 3 * D + (D if owner else 0) + 3) // 4 * 4 + 4  # (header | path codes | child branches | joint offsets along the path | [lanes of the path joints] | parent branch slot, lane of the parent link, pad)
     # compact (tree-sparse) storage of M and of its factors: column k holds the entries of its ancestors (ascending) and then the diagonal
+    # (every base-rooted component starts at a multiple of 4 values: the column solves read a component's factors with 16-byte LDS loads)
     mstart, at = [0] * n, 0
     for j in range(n):
+        if parent[j] < 0:
+            at = (at + 3) // 4 * 4
         mstart[j] = at
         at += len(m.ancestors[j]) + 1
+    at = (at + 3) // 4 * 4
     ubase = {cb: mstart[cb] for cb in comps}
     # multiply-adds of the (replicated) factorisation of the largest component: the price of keeping it wave-uniform
     factor_work = max(sum(len(m.ancestors[cb + i]) * (len(m.ancestors[cb + i]) + 1) // 2 for i in range(len(m.subtree[cb]))) for cb in comps)
@@ -122,6 +126,7 @@ def gen_branch_frame_plan(self):
             place[item] = ("x", x_at)
             x_at += size
         else:
+            sp_at = (sp_at + 3) // 4 * 4
             place[item] = ("sp", sp_at)
             sp_at += size
     # one spare set of path records at the very end takes the (branch-free) stores of the lanes that are not the first of their branch; the
@@ -1305,6 +1310,13 @@ def _emit_branch_inner(self, mode, use_thread_group=False):
                     midx[(i, k)] = len(midx)
             A("%sif (shape == %d) {" % ("" if si == 0 else "else ", si), True)
             A("T x[%d], y[%d];" % (Nc, Nc))
+            nf4 = (len(midx) + 3) // 4
+            preload = self.tuning["factor_preload"] and 4 * nf4 + 2 * Nc <= 200
+            if preload:
+                A("T F[%d]; // the component's factors, read once with 16-byte loads (its block starts at a multiple of 4 values)" % (4 * nf4))
+                A("#pragma unroll")
+                A("for (int q = 0; q < %d; q++) { __builtin_memcpy(&F[4*q], __builtin_assume_aligned(s_Uc + 4*q, 16), 4*sizeof(T)); }" % nf4)
+            UC = (lambda i_: "F[%d]" % i_) if preload else (lambda i_: "s_Uc[%d]" % i_)
             A("#pragma unroll")
             if parked:
                 A("for (int i = 0; i < %d; i++) { x[i] = s_df_du[jid*%d + cbase + i]; y[i] = s_Y[jid*%d + i]; }" % (Nc, n, NCmax))
@@ -1312,12 +1324,12 @@ def _emit_branch_inner(self, mode, use_thread_group=False):
                 A("for (int i = 0; i < %d; i++) { x[i] = s_df_du[jid*%d + cbase + i]; y[i] = s_df_du[(%d + jid)*%d + cbase + i]; }" % (Nc, n, n, n))
             for k in range(Nc - 1, 0, -1):
                 for i in an[k]:
-                    A("{ const T uu = s_Uc[%d]; x[%d] -= uu*x[%d]; y[%d] -= uu*y[%d]; }" % (midx[(i, k)], i, k, i, k))
+                    A("{ const T uu = %s; x[%d] -= uu*x[%d]; y[%d] -= uu*y[%d]; }" % (UC(midx[(i, k)]), i, k, i, k))
             for k in range(Nc):
-                A("{ const T rr = s_Uc[%d]; x[%d] *= rr; y[%d] *= rr; }" % (midx[(k, k)], k, k))
+                A("{ const T rr = %s; x[%d] *= rr; y[%d] *= rr; }" % (UC(midx[(k, k)]), k, k))
             for k in range(1, Nc):
                 for i in an[k]:
-                    A("{ const T uu = s_Uc[%d]; x[%d] -= uu*x[%d]; y[%d] -= uu*y[%d]; }" % (midx[(i, k)], k, i, k, i))
+                    A("{ const T uu = %s; x[%d] -= uu*x[%d]; y[%d] -= uu*y[%d]; }" % (UC(midx[(i, k)]), k, i, k, i))
             A("#pragma unroll")
             if parked:
                 A("for (int i = 0; i < %d; i++) { s_df_du[jid*%d + cbase + i] = -x[i]; yk[i] = -y[i]; }" % (Nc, n))
