@@ -976,6 +976,7 @@ def _emit_branch_inner(self, mode, use_thread_group=False):
         A("grid_prefix_sum(a, mku);")
         A("a[3] += gvec[0]; a[4] += gvec[1]; a[5] += gvec[2]; // (zero below tree level 0)")
         hand_down("a", "acceleration")
+        _probe(self, "vel", "v:6", "a:6", "Pd:6")
     elif kin:
         A("T v[6] = {Z, Z, Z, Z, Z, Z}, a[6] = {Z, Z, Z, Z, Z, Z};")
         A("{", True)
@@ -1279,14 +1280,21 @@ def _emit_branch_inner(self, mode, use_thread_group=False):
             A("T x[%d];" % Nc)
             A("#pragma unroll")
             A("for (int i = 0; i < %d; i++) { x[i] = (i == li) ? static_cast<T>(1) : Z; }" % Nc)
+            nf4 = (len(midx) + 3) // 4
+            preload = self.tuning["factor_preload"] and 4 * nf4 + Nc <= 200
+            if preload:
+                A("T F[%d]; // the component's factors, read once with 16-byte loads (its block starts at a multiple of 4 values)" % (4 * nf4))
+                A("#pragma unroll")
+                A("for (int q = 0; q < %d; q++) { __builtin_memcpy(&F[4*q], __builtin_assume_aligned(s_Uc + 4*q, 16), 4*sizeof(T)); }" % nf4)
+            UC = (lambda i_: "F[%d]" % i_) if preload else (lambda i_: "s_Uc[%d]" % i_)
             for k in range(Nc - 1, 0, -1):
                 for i in an[k]:
-                    A("x[%d] -= s_Uc[%d]*x[%d];" % (i, midx[(i, k)], k))
+                    A("x[%d] -= %s*x[%d];" % (i, UC(midx[(i, k)]), k))
             for k in range(Nc):
-                A("x[%d] *= s_Uc[%d];" % (k, midx[(k, k)]))
+                A("x[%d] *= %s;" % (k, UC(midx[(k, k)])))
             for k in range(1, Nc):
                 for i in an[k]:
-                    A("x[%d] -= s_Uc[%d]*x[%d];" % (k, midx[(i, k)], i))
+                    A("x[%d] -= %s*x[%d];" % (k, UC(midx[(i, k)]), i))
             A("#pragma unroll")
             A("for (int i = 0; i < %d; i++) { s_Minv[%d*jid + cbase + i] = x[i]; }" % (Nc, ld))
             self.gen_add_end_control_flow()
@@ -1397,8 +1405,10 @@ def _emit_branch_inner(self, mode, use_thread_group=False):
     A("{", True)
     A("T Pdd[6]; grid_mxm(Pdd, a, S); grid_mxm_peq(Pdd, v, Pd);")
     A("T t3[6]; grid_bmul(t3, BC, Pd); grid_rbi_mul_peq(t3, IC, Pdd, static_cast<T>(1)); grid_fxv_peq(t3, S, fC);")
+    _probe(self, "t3", "Pdd:6", "t3:6", "a:6", "fC:6")
     if owner:
         A("T t2[6]; grid_bmul(t2, BC, S); grid_rbi_mul_peq(t2, IC, Pd, static_cast<T>(2));")
+        _probe(self, "t24", "t2:6", "t4:3")
         if stream:
             A("// (half-image form: the d/dqd entries go straight into the parked columns - column-major, rows of the column's component only)")
 
