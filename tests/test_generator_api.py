@@ -100,7 +100,12 @@ def test_formulation_chosen_per_robot():
     plan = GRiDCodeGenerator(RobotModel.from_fixture("tree12")).branch_plan
     assert plan["maxlevel"] == 2 and len(plan["shapes"]) == 2 and plan["nb"] == 6 and plan["place"]["G"][0] == "sp" and plan["place"]["U"][0] == "x"
     plan = GRiDCodeGenerator(RobotModel.from_fixture("atlas")).branch_plan
-    assert plan["maxlevel"] == 1 and plan["D"] == 10 and plan["nnz"] == 150 and sorted(j for j in plan["joint_of_lane"] if j >= 0) == list(range(30))
+    # (150 entries of the tree-sparse M; every base-rooted component starts at a multiple of 4 values: 0, 108, 132 -> 156 with the padding)
+    assert plan["maxlevel"] == 1 and plan["D"] == 10 and plan["nnz"] == 156 and sorted(j for j in plan["joint_of_lane"] if j >= 0) == list(range(30))
+    assert sorted(plan["ubase"].values()) == [0, 108, 132]
+    # which walk the branch-frame robots get (algorithms/_branch_frame_gradient.branch_owner_walk): long root paths -> owner walk
+    assert plan["owner"] and plan["sp_size"] == 0
+    assert GRiDCodeGenerator(RobotModel.from_fixture("chain12")).branch_plan["owner"] and not GRiDCodeGenerator(RobotModel.from_fixture("tree12")).branch_plan["owner"]
     # every branch sits inside one 16-lane row
     for b, J in enumerate(plan["branches"]):
         lanes = [plan["joint_of_lane"].index(j) for j in J]
