@@ -33,6 +33,8 @@ TUNING_DEFAULTS = {
                                 # max|dM_dq| became 8e-4 of max|d2a_dtdq| behind the two products with M^-1 in fdsva_so on the 12-DoF tree)
     "so_split": True,           # fdsva_so of robots whose records do not fit LDS and that have several base-rooted components: host wrappers / C ABI run two kernels
                                 # (algorithms/_fdsva_so.py: gen_fdsva_so_split) - the contraction with one block per solve instead of a lane group
+    "so_hold": 0,               # fdsva_so contraction from the compact record: the results of so_hold adjacent k of a lane stay in registers and are stored together - whole runs of the result written at once (0: every k stores inside the k loop).
+                                # Measured on the 7-DoF arm @65 536 (profiles/ab/r3_fdsva_hold.jsonl): 4 cuts the HBM write traffic from 2.03x to 1.35x the result but its rolled L loop (the unrolled one spills) costs 17 % more instructions: 245 -> 258 us
     "so_blocked": True,         # fdsva_so of robots with several base-rooted components: the contraction runs per component (M^-1, df/du and the idsva_so tensors are block
                                 # diagonal over them: 7.5x fewer multiply-adds on the 30-DoF humanoid, 64x on the quadruped; algorithms/_fdsva_so.py: _BLOCKED)
     "so_fused": True,           # fdsva_so of serial chains: the forward-dynamics-gradient inner goes straight on to the idsva_so main loops with the per-joint quantities it holds
@@ -449,7 +451,7 @@ class GRiDCodeGenerator:
     def so_wide_lanes(self):
         """Lane-group width of the nested `wide` instance that carries the second-order kernels (tuning so_lanes), or None."""
         want = self.tuning["so_lanes"]
-        if self.nested or want == "off" or self.lanes_per_solve > 16 or not self.gen_idsva_so_available() or int(self.tuning["debug_stop"]) != 0:
+        if self.nested or want == "off" or self.lanes_per_solve > 16 or not self.gen_idsva_so_available() or int(self.tuning["debug_stop"]) not in (0, 31):
             return None
         if hasattr(self, "_so_wide_cache"):
             return self._so_wide_cache

@@ -95,6 +95,56 @@ for (int k = @K0@; k < @N@; k += @KSTEP@) {
 """
 
 
+# _COMPACT with the results of ALL k of a lane held in registers and stored at the end, (i, tensor) by (i, tensor): the lane group then writes the 4 n^2-byte run of an
+# (i, tensor) within a few instructions.  With the k loop outside, one store instruction wrote 8 n bytes of every run and came back to it an iteration (~1.5 k
+# instructions) later: 45 MB of half-written lines in flight at 65 536 solves, more than the L2 holds - HBM write traffic 2.0x the result (profiles/r03_so_iiwa14_pmc.txt)
+_COMPACT_HELD_HEAD = """
+const T *q2c = s_idsva_so + @Q2@, *qd2c = s_idsva_so + @QD2@, *tvq = s_idsva_so + @VQ@, *mqc = s_idsva_so + @MQ@;
+@SPLIT@
+T fq_j[@N@], fv_j[@N@], mi_j[@N@]; // column j of df/dq and of df/dqd, row j of M^-1
+#pragma unroll
+for (int p = 0; p < @N@; p++) { fq_j[p] = s_df_du[j*@N@ + p]; fv_j[p] = s_df_du[(@N@ + j)*@N@ + p]; mi_j[p] = s_Minv[j*@LD@ + p]; }
+"""
+_COMPACT_HELD_K = """
+T oq@KK@[@N@], oc@KK@[@N@], ov@KK@[@N@], ot@KK@[@N@]; // the results (i, k, j) of this lane's k = @K0@ + @KSTEP@*@KK@ (sign flipped at the store)
+{
+    const int kx = @K0@ + @KSTEP@*@KK@; const int k = (kx < @N@) ? kx : 0; // (a lane whose last k is past the end computes k = 0 again and stores nothing)
+    T fq_k[@N@];
+    #pragma unroll
+    for (int p = 0; p < @N@; p++) { fq_k[p] = s_df_du[k*@N@ + p]; }
+    const int hi = (k > j) ? k : j, lo = (k > j) ? j : k, kj = (hi*(hi + 1) >> 1) + lo; // (k, j) in the symmetric tensors
+    #pragma unroll
+    for (int i = 0; i < @N@; i++) { oq@KK@[i] = oc@KK@[i] = ov@KK@[i] = ot@KK@[i] = static_cast<T>(0); }
+    #pragma unroll 1
+    for (int L = 0; L < @N@; L++) { // inner_dq, inner_cross, d2tau_dvdv, inner_tau at (L, k, j), then their share of every row i
+        T aq = q2c[L*@TRI@ + kj], ac = tvq[(L*@N@ + k)*@N@ + j], at = static_cast<T>(0);
+        const T av = qd2c[L*@TRI@ + kj];
+        #pragma unroll
+        for (int p = 0; p < @N@; p++) {
+            const int plo = (L < p) ? L : p, phi = (L < p) ? p : L, base = ((phi*(phi + 1) >> 1) + plo)*@N@; // (compile-time after unrolling)
+            const T mk_ = mqc[base + k], mj_ = mqc[base + j]; // (slots of structural zeros are never written: read, then discarded by the select)
+            const T mk = (k > plo) ? mk_ : static_cast<T>(0), mj = (j > plo) ? mj_ : static_cast<T>(0);
+            aq += mj*fq_k[p] + mk*fq_j[p]; ac += mk*fv_j[p]; at += mk*mi_j[p];
+        }
+        #pragma unroll
+        for (int i = 0; i < @N@; i++) { const T mi = s_Minv[L*@LD@ + i]; oq@KK@[i] += mi*aq; oc@KK@[i] += mi*ac; ov@KK@[i] += mi*av; ot@KK@[i] += mi*at; }
+    }
+    asm volatile("" ::: "memory"); // (the next k re-reads its operands from LDS: values kept live across the bodies would not fit the register file)
+}
+"""
+
+
+def _compact_held(kt, hold):
+    """The held form for kt values of k per lane: a rolled loop over groups of `hold` ADJACENT k (lane (j, kh) of a group takes k = hold*KSTEP*t + hold*kh + 0..hold-1), the body
+    once per k of the group (distinct register arrays), then the group's stores (i, tensor) by (i, tensor): hold*KSTEP*n values of a run at once."""
+    text = _COMPACT_HELD_HEAD + "#pragma unroll 1\nfor (int t = 0; t < %d; t++) {\n" % (-(-kt // hold))
+    text += "".join(_COMPACT_HELD_K.replace("@K0@ + @KSTEP@*@KK@", "%d*@KSTEP@*t + %d*@K0@ + @KK@" % (hold, hold)).replace("@KK@", str(kk)) for kk in range(hold))
+    for kk in range(hold):  # (one predicated block per k: the group's lanes write adjacent k, the blocks follow each other within a few dozen instructions)
+        text += "{ const int k = %d*@KSTEP@*t + %d*@K0@ + %d;\n  if (own && k < @N@) {\n    T *dst = &df2[k*@N@ + j];\n    #pragma unroll\n    for (int i = 0; i < @N@; i++) { dst[i*@N@*@N@] = -oq%d[i]; dst[@N3@ + i*@N@*@N@] = -ov%d[i]; dst[2*@N3@ + i*@N@*@N@] = -oc%d[i]; dst[3*@N3@ + i*@N@*@N@] = -ot%d[i]; }\n  } }\n" % (hold, hold, kk, kk, kk, kk, kk)
+    return text + "}\n"
+
+
+
 # robots with several base-rooted components (a quadruped's legs; the humanoid's torso tree and legs): a fixed base decouples them, so qdd_i and all
 # its derivatives involve only the joints of the component of joint i - M^-1, df/du and the idsva_so tensors are block diagonal over the components
 # (contiguous joint ranges in DFS pre-order) and so is the result.  Every loop of the contraction runs over the component of the lane's joint
@@ -183,7 +233,12 @@ def gen_fdsva_so_inner(self, use_thread_group=False):
     self.gen_add_code_line("void fdsva_so_inner(T *df2, const T *s_idsva_so, const T *s_Minv, const T *s_df_du, const int lane, const bool active) {", True)
     compact = self.gen_idsva_so_compact()
     blocked = self.gen_fdsva_so_components()
-    lines = (_COMPACT if compact else _BLOCKED if blocked is not None else _ROLLED if n > 12 else """
+    G0 = self.lanes_per_solve
+    kstep = 2 if ((n <= 12 or compact) and G0 // 2 >= n) else 1
+    kt = -(-n // kstep)  # k values per lane
+    hold = min(int(self.tuning["so_hold"]), kt)
+    held = compact and hold > 0 and 4 * n * hold <= 140 and int(self.tuning["debug_stop"]) != 31
+    lines = ((_compact_held(kt, hold) if held else _COMPACT) if compact else _BLOCKED if blocked is not None else _ROLLED if n > 12 else """
 const T *tqq = s_idsva_so, *tvv = s_idsva_so + @N3@, *tvq = s_idsva_so + 2*@N3@, *dM = s_idsva_so + 3*@N3@;
 @SPLIT@
 T fq_j[@N@], fv_j[@N@], mi_j[@N@]; // column j of df/dq and of df/dqd, row j of M^-1
@@ -215,6 +270,9 @@ for (int k = @K0@; k < @N@; k += @KSTEP@) {
     }
 }
 """)
+    if compact and int(self.tuning["debug_stop"]) == 31:  # timing ablation (wrong results): only one of the four result tensors is stored
+        lines = lines.replace("df2[e] = -oq; df2[@N3@ + e] = -ov; df2[2*@N3@ + e] = -oc; df2[3*@N3@ + e] = -ot;",
+                              "df2[e] = -oq; if (df2 == nullptr) { df2[@N3@ + e] = -ov; df2[2*@N3@ + e] = -oc; df2[3*@N3@ + e] = -ot; }")
     G = self.lanes_per_solve
     if (n <= 12 or compact) and G // 2 >= n:  # lane groups at least twice as wide as the robot has joints (the `wide` instances): the two halves of the group take alternate k
         lines = lines.replace("@SPLIT@", "const int jh = lane %% %d, kh = lane / %d; // joint and k parity of this lane\nconst int j = (jh < @N@) ? jh : 0;\nconst bool own = active && (jh < @N@);" % (G // 2, G // 2)).replace("@K0@", "kh").replace("@KSTEP@", "2")

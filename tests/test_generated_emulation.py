@@ -379,11 +379,12 @@ def test_emulated_fdsva_so(name, libs, golden):
             assert np.abs(got[t] - ref[t]).max() <= TOL * max(np.abs(ref[t]).max(), 1e-3), (k, t)
 
 
-@pytest.mark.parametrize("name,tuning", [("atlas", {"so_split": False}), ("hyq", {"so_blocked": False}), ("tree12", {"so_origin": "base"})])
+@pytest.mark.parametrize("name,tuning", [("atlas", {"so_split": False}), ("hyq", {"so_blocked": False}), ("tree12", {"so_origin": "base"}), ("iiwa14", {"so_hold": 4})])
 def test_emulated_fdsva_so_variants_agree_with_the_shipped_form(name, tuning, libs, golden):
     """The forms the shipped second-order kernels replaced stay available as tuning variants and give the same tensors: the single-kernel fdsva_so of the
     30-DoF humanoid (the C ABI runs prepare + contract kernels there; the single fdsva_so_kernel is what a caller launching it himself gets), the dense
-    (not block-diagonal) contraction, and the tree form about the base origin (fp32: equal to ~1e-4 of the tensor's largest entry only - the reason it was replaced)."""
+    (not block-diagonal) contraction, the tree form about the base origin (fp32: equal to ~1e-4 of the tensor's largest entry only - the reason it was replaced), and the
+    compact-record contraction that holds the results of four adjacent k in registers and stores them together (so_hold: less write traffic, more instructions - not shipped)."""
     g = golden(name)
     a = libs(name)
     b = emu_library(name, max_timesteps=8, tuning=tuning)
