@@ -76,7 +76,8 @@ for (int k = @K0@; k < @N@; k += @KSTEP@) {
         #pragma unroll
         for (int p = 0; p < @N@; p++) {
             const int plo = (L < p) ? L : p, phi = (L < p) ? p : L, base = ((phi*(phi + 1) >> 1) + plo)*@N@; // (compile-time after unrolling)
-            const T mk = (k > plo) ? mqc[base + k] : static_cast<T>(0), mj = (j > plo) ? mqc[base + j] : static_cast<T>(0);
+            const T mk_ = mqc[base + k], mj_ = mqc[base + j]; // (slots of structural zeros are never written: read, then discarded by the select - no exec-masked load blocks)
+            const T mk = (k > plo) ? mk_ : static_cast<T>(0), mj = (j > plo) ? mj_ : static_cast<T>(0);
             aq += mj*fq_k[p] + mk*fq_j[p]; ac += mk*fv_j[p]; at += mk*mi_j[p];
         }
         rq[L] = aq; rc[L] = ac; rt[L] = at; rv[L] = qd2c[L*@TRI@ + kj];
