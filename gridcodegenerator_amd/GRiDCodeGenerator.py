@@ -451,7 +451,7 @@ class GRiDCodeGenerator:
     def so_wide_lanes(self):
         """Lane-group width of the nested `wide` instance that carries the second-order kernels (tuning so_lanes), or None."""
         want = self.tuning["so_lanes"]
-        if self.nested or want == "off" or self.lanes_per_solve > 16 or not self.gen_idsva_so_available() or int(self.tuning["debug_stop"]) not in (0, 31):
+        if self.nested or want == "off" or self.lanes_per_solve > 16 or not self.gen_idsva_so_available() or int(self.tuning["debug_stop"]) not in (0, 30, 31, 32):
             return None
         if hasattr(self, "_so_wide_cache"):
             return self._so_wide_cache

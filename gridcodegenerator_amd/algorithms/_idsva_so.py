@@ -1056,7 +1056,11 @@ def gen_idsva_so_kernel(self, use_thread_group=False, use_qdd_input=False, singl
         else:
             self.gen_kernel_save_result_single_timing("idsva_so", 4 * n3, use_thread_group)
     elif compact:
+        if int(self.tuning["debug_stop"]) == 32:  # timing ablation (wrong results): everything computed and staged, the record never leaves the CU
+            self.gen_add_code_line("if (gravity < static_cast<T>(-1e30)) {", True)
         self.gen_kernel_save_result_expanded("idsva_so", 4 * n3, stage, "grid_so_expand", use_thread_group)
+        if int(self.tuning["debug_stop"]) == 32:
+            self.gen_add_end_control_flow()
     else:
         self.gen_kernel_save_result("idsva_so", 4 * n3, 4 * n3, use_thread_group)
     if not single_call_timing:

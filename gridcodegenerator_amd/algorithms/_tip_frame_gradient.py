@@ -982,7 +982,7 @@ def gen_tip_frame_components(self, use_thread_group=False):
 def gen_tip_frame_fused_so(self):
     """True where fdsva_so runs the fused inner forward_dynamics_gradient_inner_tip_so (one chain, the balanced dot-product loops, tuning so_fused)."""
     return bool(self.tip_frame and not getattr(self, "branch_frame", False) and self.tip_nseg == 1 and self.tuning["so_fused"] and self.gen_idsva_so_mode() == "chain"
-                and self.tuning["so_mapping"] == "balanced" and self.tuning["so_loops"] == "dots" and int(self.tuning["debug_stop"]) in (0, 31))
+                and self.tuning["so_mapping"] == "balanced" and self.tuning["so_loops"] == "dots" and int(self.tuning["debug_stop"]) in (0, 30, 31, 32))
 
 
 def gen_tip_frame_gradient(self, use_thread_group=False):
