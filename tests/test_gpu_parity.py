@@ -327,6 +327,41 @@ def test_non_default_generation_variants_on_gpu(tuning, torch_cuda, golden, tmp_
     lib.close()
 
 
+@pytest.mark.parametrize("name,tuning", [("tree12", {"branch_walk": "owner"}), ("chain12", {"branch_walk": "path"})])
+def test_the_other_walk_of_the_branch_frame_path_on_gpu(name, tuning, torch_cuda, golden, tmp_path):
+    """The branch-frame kernels have two forms of their walks along the root paths (algorithms/_branch_frame_gradient.branch_owner_walk): the one a fixture does NOT get by
+    default is built here and run on real wave64 hardware - the owner walk's cross-lane reads (ds_bpermute inside 16-lane groups, two hand-downs and two branch crossings on
+    the three-level tree) and the path walk on the 12-joint chain - goldens plus 3 000 random states against the fp64 oracle, all first-order kernels of the tree."""
+    from oracle.rbd_oracle import Oracle
+
+    so = build_library(name, build_dir=str(tmp_path), tuning=dict({"so_lanes": "off"}, **tuning))
+    lib = GridLibrary(so, device=0, max_timesteps=4096)
+    g = golden(name)
+    n = lib.n
+    x = np.hstack([g["q"], g["qd"], g["u"]]).astype(np.float32)
+    assert per_solve_err(run_fd_grad(torch_cuda, lib, x), np.stack([g["df_du"][k].T.reshape(-1) for k in range(x.shape[0])])) <= TOL
+    xs = inputs(n, 3000, seed=5)
+    orc = Oracle(RobotModel.from_fixture(name))
+    ref, _ = orc.fd_grad_batch(xs.astype(np.float64))
+    assert per_solve_err(run_fd_grad(torch_cuda, lib, xs), ref) <= TOL
+    if name == "tree12":  # the stand-alone kernels share the emitter
+        torch = torch_cuda
+        st = torch.cuda.current_stream().cuda_stream
+        N = x.shape[0]
+        d_x, d_qdd = torch.from_numpy(x).cuda(), torch.from_numpy(g["qdd"].astype(np.float32)).cuda()
+        c = torch.empty((N, n), dtype=torch.float32, device="cuda")
+        lib.inverse_dynamics_device(d_x, d_qdd, N, c, stream=st)
+        dc = torch.empty((N, 2 * n * n), dtype=torch.float32, device="cuda")
+        lib.inverse_dynamics_gradient_device(d_x, d_qdd, N, dc, stream=st)
+        mi = torch.empty((N, n * n), dtype=torch.float32, device="cuda")
+        lib.direct_minv_device(d_x, N, mi, stream=st)
+        torch.cuda.synchronize()
+        assert per_solve_err(c.cpu().numpy(), g["c2"]) <= TOL
+        assert per_solve_err(dc.cpu().numpy(), np.stack([g["dc_du"][k].T.reshape(-1) for k in range(N)])) <= TOL
+        assert per_solve_err(mi.cpu().numpy(), np.stack([g["Minv_upper"][k].T.reshape(-1) for k in range(N)])) <= TOL
+    lib.close()
+
+
 @pytest.mark.parametrize("name", ["iiwa14", "arm6", "chain12", "chain8", "hyq", "tree12", "atlas", "mixed5"])
 def test_idsva_so_matches_the_restated_reference_algorithm(name, torch_cuda, libs, golden):
     """SURVEY.md section 8(f) rank 3 (serial chains: tip-frame form; the quadruped, the 12-DoF tree and the 30-DoF humanoid: tree form - the humanoid's
