@@ -176,6 +176,60 @@ def measured_copy_bandwidth(torch, dev):
     return 2.0 * nbytes * reps / (e0.elapsed_time(e1) * 1e-3) / 1e9
 
 
+def other_configs(torch):
+    """BASELINE.json's secondary configs on this GPU, device-resident, HIP events around 20 launches after 0.15 s of warm-up launches each - diagnostics next to the headline,
+    never `value`: config 3 (12-DoF quadruped @4 096), config 4 (30-DoF humanoid @16 384 on ONE GPU), config 5 (second order, 7-DoF arm @65 536 on ONE GPU)."""
+    from gridcodegenerator_amd import RobotModel
+    from gridcodegenerator_amd.runtime import load
+
+    out = {}
+    st = torch.cuda.current_stream().cuda_stream
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+
+    def timed(f):
+        t_end = time.perf_counter() + 0.15  # (clock warm, as before the headline's timed region)
+        while time.perf_counter() < t_end:
+            for _ in range(10):
+                f()
+            torch.cuda.synchronize()
+        e0.record()
+        for _ in range(20):
+            f()
+        e1.record()
+        torch.cuda.synchronize()
+        return round(1e3 * e0.elapsed_time(e1) / 20, 2)
+
+    for name, N, second_order in (("hyq", 4096, False), ("atlas", 16384, False), ("iiwa14", 65536, True)):
+        n = RobotModel.from_fixture(name).n
+        lib = load(name, max_timesteps=N)
+        rng = np.random.default_rng(0)
+        x = torch.from_numpy(np.hstack([rng.uniform(-np.pi, np.pi, (N, n)), rng.uniform(-2, 2, (N, n)), rng.uniform(-10, 10, (N, n))]).astype(np.float32)).cuda()
+        r = {}
+        if second_order:
+            qdd = torch.from_numpy(rng.uniform(-5, 5, (N, n)).astype(np.float32)).cuda()
+            so = torch.empty((N, 4 * n ** 3), dtype=torch.float32, device="cuda")
+            by = 4 * (3 * n + 4 * n ** 3) * N
+            for kern, f in (("idsva_so", lambda: lib.idsva_so_device(x, qdd, N, so, stream=st)), ("fdsva_so", lambda: lib.fdsva_so_device(x, N, so, stream=st))):
+                us = timed(f)
+                r[kern] = {"us_per_launch": us, "solves_per_s": round(N / us * 1e6), "hbm_frac_of_8TBps": round(by / us / 1e3 / 8000, 3)}
+            del so, qdd
+        else:
+            o = torch.empty((N, 2 * n * n), dtype=torch.float32, device="cuda")
+            us = timed(lambda: lib.forward_dynamics_gradient_device(x, N, o, stream=st))
+            r["forward_dynamics_gradient"] = {"us_per_launch": us, "solves_per_s": round(N / us * 1e6), "hbm_frac_of_8TBps": round(4 * (3 * n + 2 * n * n) * N / us / 1e3 / 8000, 3)}
+            if name == "atlas":
+                mi = torch.empty((N, n * n), dtype=torch.float32, device="cuda")
+                us = timed(lambda: lib.direct_minv_device(x, N, mi, stream=st))
+                r["direct_minv"] = {"us_per_launch": us, "solves_per_s": round(N / us * 1e6)}
+            else:
+                q = torch.empty((N, n), dtype=torch.float32, device="cuda")
+                us = timed(lambda: lib.aba_device(x, N, q, stream=st))
+                r["aba"] = {"us_per_launch": us, "solves_per_s": round(N / us * 1e6)}
+        out["%s @%d" % (name, N)] = r
+        lib.close()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -380,6 +434,8 @@ def main():
             line["end_to_end_pinned_note"] = "same call, caller's buffers from grid_host_alloc (page-locked): chunked H2D | kernel | D2H pipeline; the %.1f MB D2H at PCIe rate is the floor" % (xh.shape[0] * 2 * n * n * 4 / 1e6)
             assert np.array_equal(op, lib.forward_dynamics_gradient_host(xh))
             del xp, op
+        if world == 1 and not args.no_extras:
+            line["other_configs"] = other_configs(torch)
         if not args.no_cpu_baseline and world == 1:
             # the only place the oracle (test infrastructure) is touched: the CPU baseline leg, which also spot-checks the GPU result
             line["cpu_baseline"] = cpu_baseline(robot, r["x"])
