@@ -435,7 +435,10 @@ def main():
             assert np.array_equal(op, lib.forward_dynamics_gradient_host(xh))
             del xp, op
         if world == 1 and not args.no_extras:
-            line["other_configs"] = other_configs(torch)
+            try:  # (diagnostics: a failure here must not cost the headline line)
+                line["other_configs"] = other_configs(torch)
+            except Exception as exc:
+                line["other_configs"] = {"error": repr(exc)}
         if not args.no_cpu_baseline and world == 1:
             # the only place the oracle (test infrastructure) is touched: the CPU baseline leg, which also spot-checks the GPU result
             line["cpu_baseline"] = cpu_baseline(robot, r["x"])
